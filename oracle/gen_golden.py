@@ -1,0 +1,242 @@
+"""Generate tests/golden/*.npz by RUNNING the reference's own code on CPU.
+
+Build-container only: /root/reference does not travel, so the vectors written
+here are committed and everything else (oracle, HIP path) is checked against them.
+Only inputs and outputs are stored - never reference source.
+
+How the reference is imported: models.py needs only torch + numpy.  trainers.py
+pulls in utilities.py / metrics.py, whose third-party imports (h5py, gensim,
+pycocoevalcap, tensorboard) are absent here and untouched by the A2C path, so
+empty placeholder modules are registered for those names; the tensorboard
+placeholder's SummaryWriter records the (tag, value, step) triples, which are the
+reference's per-minibatch outputs (trainers.py:489-492).
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/)
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "image-captioning-through-rl_amd"))
+import synthetic  # noqa: E402
+
+SCALARS = []
+
+
+class _Writer:
+    def __init__(self, *a, **k):
+        pass
+
+    def add_scalar(self, tag, value, step):
+        SCALARS.append((tag, float(value), int(step)))
+
+
+def _placeholder(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+    _placeholder("h5py")
+    g = _placeholder("gensim")
+    g.downloader = _placeholder("gensim.downloader")
+    g.models = _placeholder("gensim.models", KeyedVectors=_Any)
+    g.utils = _placeholder("gensim.utils", simple_preprocess=lambda *a, **k: [])
+    _placeholder("pycocoevalcap")
+    for sub, cls in (("bleu", "Bleu"), ("rouge", "Rouge"), ("cider", "Cider"), ("meteor", "Meteor")):
+        _placeholder("pycocoevalcap." + sub)
+        _placeholder("pycocoevalcap.%s.%s" % (sub, sub), **{cls: _Any})
+    _placeholder("torch.utils.tensorboard", SummaryWriter=_Writer)
+    sys.path.insert(0, REF)
+    models = importlib.import_module("models")
+    trainers = importlib.import_module("trainers")
+    return models, trainers
+
+
+def build_nets(models, vocab, fdim, seed):
+    """Reference modules, widened to feature_dim (models.py:160, 250 hard-wire 512),
+    with every parameter overwritten from the seeded NumPy recipe."""
+    w2i = synthetic.make_word_to_idx(vocab)
+    pol = models.PolicyNetwork(w2i, input_dim=fdim)
+    val = models.ValueNetwork(w2i)
+    rew = models.RewardNetwork(w2i)
+    if fdim != 512:
+        val.linear1 = torch.nn.Linear(fdim + 512, 512)
+        rew.visual_embed = torch.nn.Linear(fdim, 512)
+    for net, kind in ((pol, "policy"), (val, "value"), (rew, "reward")):
+        params = synthetic.make_params(kind, vocab, fdim, seed)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(params.keys()), (list(sd.keys()), list(params.keys()))
+        for k in sd:
+            assert tuple(sd[k].shape) == params[k].shape, k
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return pol, val, rew
+
+
+PROBES = 48
+
+
+def probe_idx(name, size):
+    rs = np.random.RandomState(abs(hash_name(name)) % (2 ** 31))
+    return rs.randint(0, size, size=min(PROBES, size))
+
+
+def hash_name(name):
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+    return h
+
+
+def summarize(prefix, tensors, out):
+    for name, t in tensors.items():
+        a = t.detach().double().numpy().ravel()
+        out["%s/%s/l2" % (prefix, name)] = np.array(np.sqrt((a * a).sum()))
+        out["%s/%s/sum" % (prefix, name)] = np.array(a.sum())
+        out["%s/%s/probe" % (prefix, name)] = a[probe_idx(name, a.size)]
+
+
+def run_a2c(models, trainers, cfg, epochs, level=None):
+    n, vocab, caplen, fdim, seed = cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"]
+    pol, val, rew = build_nets(models, vocab, fdim, seed)
+    rew.requires_grad_(False)
+    rew.train(False)
+    a2c = models.AdvantageActorCriticNetwork(val, pol)
+    a2c.train(True)
+    opt = torch.optim.Adam(a2c.parameters(), lr=0.0001)
+    data = synthetic.make_train_data(n, vocab, caplen, fdim, seed)
+
+    rec = {"values": [], "logits": [], "rewards": [], "tokens": [], "batches": []}
+    def forward_spy(module, inputs, output):
+        rec["values"].append(output[0].detach().clone())
+        rec["logits"].append(output[1].detach().clone())
+
+    hook = a2c.register_forward_hook(forward_spy)
+    orig_rewards = trainers.GetRewards
+    orig_batches = trainers.get_coco_minibatches
+
+    def rewards_spy(features, captions, reward_network):
+        r = orig_rewards(features, captions, reward_network)
+        rec["rewards"].append(r.detach().clone())
+        rec["tokens"].append(captions.detach().clone())
+        return r
+
+    def batches_spy(d, batch_size=100, split="train"):
+        for caps, feats, urls in orig_batches(d, batch_size=batch_size, split=split):
+            rec["batches"].append((np.array(caps), np.array(feats)))
+            yield caps, feats, urls
+
+    trainers.GetRewards = rewards_spy
+    trainers.get_coco_minibatches = batches_spy
+    trainers.save_a2c_model = lambda *a, **k: None
+    del SCALARS[:]
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    try:
+        if level is None:
+            trainers.a2c_training(data, a2c, rew, opt, "/tmp/plots", [], n, epochs)
+        else:
+            trainers.a2c_curriculum_training(data, a2c, rew, opt, "/tmp/plots", [], n, epochs, [level])
+    finally:
+        hook.remove()
+        trainers.GetRewards = orig_rewards
+        trainers.get_coco_minibatches = orig_batches
+    return a2c, rec, list(SCALARS)
+
+
+def golden_for(models, trainers, cfg, level=None):
+    n, vocab, caplen = cfg["n"], cfg["vocab"], cfg["caplen"]
+    steps = (caplen - 1) if level is None else level
+    out = {"cfg": np.array([cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"],
+                            -1 if level is None else level])}
+    # ---- one optimizer step: per-step internals, gradients, post-Adam parameters
+    a2c, rec, scal = run_a2c(models, trainers, cfg, 1, level)
+    caps, feats = rec["batches"][0]
+    out["captions"] = caps.astype(np.int64)
+    out["features"] = feats.astype(np.float32)
+    out["uniforms"] = synthetic.make_uniforms(cfg["seed"], steps * n)
+    out["tokens"] = rec["tokens"][-1].numpy().astype(np.int64)
+    logits = torch.stack([l[:, 0, :] for l in rec["logits"]], 0)  # [steps, N, V]
+    out["logits"] = logits.numpy()
+    toks = torch.from_numpy(out["tokens"])
+    p0 = out["tokens"].shape[1] - steps
+    probs = torch.softmax(logits, dim=2)
+    acts = toks[:, p0:].t().unsqueeze(2)  # [steps, N, 1]
+    out["log_probs"] = torch.log(probs.gather(2, acts))[:, :, 0].t().numpy()
+    out["values"] = torch.cat(rec["values"], 1).numpy()
+    out["rewards"] = torch.cat(rec["rewards"], 1).numpy()
+    out["scalars_step1"] = np.array([s[1] for s in scal[:3]])
+    # how close each draw sat to a CDF edge (a fragile draw may legitimately flip)
+    dist = probs.to(torch.float32).numpy()
+    u = out["uniforms"].reshape(steps, n)
+    edge = np.zeros((steps, n))
+    for k in range(steps):
+        for i in range(n):
+            cdf = np.cumsum(dist[k, i].astype(np.float64))
+            cdf /= cdf[-1]
+            edge[k, i] = np.min(np.abs(cdf - u[k, i]))
+    out["cdf_edge"] = edge
+    summarize("grad", {k: p.grad for k, p in a2c.named_parameters() if p.grad is not None}, out)
+    summarize("param1", dict(a2c.named_parameters()), out)
+    # ---- two optimizer steps: scalars of step 2 and parameter summaries
+    if level is None:
+        a2c2, rec2, scal2 = run_a2c(models, trainers, cfg, 2, level)
+        out["scalars_step2"] = np.array([s[1] for s in scal2[3:6]])
+        caps2, feats2 = rec2["batches"][1]
+        out["captions_step2"] = caps2.astype(np.int64)
+        out["features_step2"] = feats2.astype(np.float32)
+        out["tokens_step2"] = rec2["tokens"][-1].numpy().astype(np.int64)
+        summarize("param2", dict(a2c2.named_parameters()), out)
+    return out
+
+
+def golden_greedy(models, trainers, cfg):
+    n, vocab, caplen, fdim, seed = cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"]
+    pol, _, _ = build_nets(models, vocab, fdim, seed)
+    feats, caps = synthetic.make_minibatch(n, vocab, caplen, fdim, seed)
+    with torch.no_grad():
+        toks = trainers.GenerateCaptionsGreedy(feats, caps, pol)
+        logits = pol(torch.tensor(feats).unsqueeze(0), toks[:, :-1])
+        top2 = logits.topk(2, dim=2).values
+    return {"greedy_tokens": toks.numpy().astype(np.int64),
+            "greedy_margins": (top2[..., 0] - top2[..., 1]).numpy()}
+
+
+CONFIGS = [
+    dict(name="n4_v100_l10_f512_s0", n=4, vocab=100, caplen=10, fdim=512, seed=0),
+    dict(name="n4_v100_l10_f512_s1", n=4, vocab=100, caplen=10, fdim=512, seed=1),
+    dict(name="n4_v100_l10_f4096_s0", n=4, vocab=100, caplen=10, fdim=4096, seed=0),
+    dict(name="n8_v257_l20_f2048_s0", n=8, vocab=257, caplen=20, fdim=2048, seed=0),
+]
+
+
+def main():
+    models, trainers = import_reference()
+    gdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gdir, exist_ok=True)
+    for cfg in CONFIGS:
+        out = golden_for(models, trainers, cfg)
+        out.update(golden_greedy(models, trainers, cfg))
+        np.savez_compressed(os.path.join(gdir, "a2c_%s.npz" % cfg["name"]), **out)
+        print("wrote", cfg["name"], "loss", out["scalars_step1"])
+    cfg = dict(name="n4_v100_l10_f512_s0", n=4, vocab=100, caplen=10, fdim=512, seed=0)
+    out = golden_for(models, trainers, cfg, level=3)
+    np.savez_compressed(os.path.join(gdir, "a2c_curriculum3_%s.npz" % cfg["name"]), **out)
+    print("wrote curriculum level 3", out["scalars_step1"])
+
+
+if __name__ == "__main__":
+    main()
