@@ -1,0 +1,233 @@
+// f32 GEMM on the exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// C[M,N] = (acc ? C : 0) + A[M,K]*B[K,N] + bias[n] + bias2[n].
+// 256 threads = 4 waves in a 2x2 arrangement; each wave owns a (BM/2)x(BN/2) block of
+// the BMxBN output tile as TMxTN accumulator tiles of 32x32.  K is walked in steps of
+// 32 through double-buffered LDS; the next K-step's global loads are issued before the
+// current step's MFMAs and written to the other LDS buffer after them (one barrier per
+// K-step).
+//
+// Either operand may be stored with k contiguous ("MK": [rows][ld], an nn.Linear
+// weight or an activation matrix) or with the row index contiguous ("KM": [K][ld], a
+// transposed view).  MK tiles sit in LDS as [row][36] (pad 4: ds_read_b128 of 16
+// different rows at one k offset is conflict-free), KM tiles as [k][rows].
+// The MFMA sums over k in any order, so within a 16-k group lane-half h supplies
+// k = 8h + j at MFMA step j for BOTH operands: an MK operand then reads its 8 values
+// with two ds_read_b128, a KM operand with eight ds_read_b32 of 32 consecutive floats.
+#include "icrl_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int MK_LD = 36;
+
+struct GemmArgs {
+    const float* A; int64_t lda; const int64_t* a_rows;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int M, N, K;
+    const float* bias; const float* bias2;
+    int accumulate;
+    int a_vec, b_vec;  // 1 = 16-byte loads are aligned for this operand
+};
+
+// Load 4 consecutive floats p[0..3] of which the first `valid` exist.
+__device__ __forceinline__ float4 load4(const float* p, int valid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid >= 4 && vec) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        if (valid > 0) v.x = p[0];
+        if (valid > 1) v.y = p[1];
+        if (valid > 2) v.z = p[2];
+        if (valid > 3) v.w = p[3];
+    }
+    return v;
+}
+
+// Global -> registers for one operand tile of ROWS x 32 (R = ROWS/32 float4 per thread).
+template <int ROWS, bool KM>
+__device__ __forceinline__ void tile_load(float4 (&r)[ROWS / 32], const float* base, int64_t ld,
+                                          const int64_t* gather, int row0, int nrows, int k0, int K,
+                                          bool vec, int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int f = tid + 256 * i;
+        if (!KM) {
+            const int row = f >> 3, kq = f & 7;
+            const int gr = row0 + row, gk = k0 + 4 * kq;
+            if (gr < nrows && gk < K) {
+                const int64_t src = gather ? gather[gr] : (int64_t)gr;
+                r[i] = load4(base + src * ld + gk, K - gk, vec);
+            } else {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int k = f / (ROWS / 4), m4 = f % (ROWS / 4);
+            const int gk = k0 + k, gr = row0 + 4 * m4;
+            if (gk < K && gr < nrows) {
+                r[i] = load4(base + (int64_t)gk * ld + gr, nrows - gr, vec);
+            } else {
+                r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+template <int ROWS, bool KM>
+__device__ __forceinline__ void tile_store(float* lds, const float4 (&r)[ROWS / 32], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int f = tid + 256 * i;
+        if (!KM) {
+            const int row = f >> 3, kq = f & 7;
+            *reinterpret_cast<float4*>(lds + row * MK_LD + 4 * kq) = r[i];
+        } else {
+            const int k = f / (ROWS / 4), m4 = f % (ROWS / 4);
+            *reinterpret_cast<float4*>(lds + k * ROWS + 4 * m4) = r[i];
+        }
+    }
+}
+
+// Fragment values for one 16-k group g: v[j] = tile[row][16g + 8h + j], j = 0..7.
+template <int ROWS, bool KM>
+__device__ __forceinline__ void frag_read(float (&v)[8], const float* lds, int row, int g, int h) {
+    if (!KM) {
+        const float4 a = *reinterpret_cast<const float4*>(lds + row * MK_LD + 16 * g + 8 * h);
+        const float4 b = *reinterpret_cast<const float4*>(lds + row * MK_LD + 16 * g + 8 * h + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = lds[(16 * g + 8 * h + j) * ROWS + row];
+    }
+}
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_TILE = A_KM ? BK * BM : BM * MK_LD;
+    constexpr int B_TILE = B_KM ? BK * BN : BN * MK_LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order: consecutive tiles of one output row-panel share A rows, so
+    // give each XCD (blocks b, b+8, ... share one) a contiguous run of tiles.
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    const int nk = (g.K + BK - 1) / BK;
+    tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, 0, g.K, g.a_vec, tid);
+    tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, 0, g.K, g.b_vec, tid);
+    tile_store<BM, A_KM>(lds, ra, tid);
+    tile_store<BN, B_KM>(lds + A_TILE, rb, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
+        const float* lb = la + A_TILE;
+        if (kt + 1 < nk) {
+            tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, (kt + 1) * BK, g.K, g.a_vec, tid);
+            tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, (kt + 1) * BK, g.K, g.b_vec, tid);
+        }
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            float av[TM][8], bv[TN][8];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                frag_read<BM, A_KM>(av[i], la, wr * (BM / 2) + i * 32 + l31, grp, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                frag_read<BN, B_KM>(bv[j], lb, wc * (BN / 2) + j * 32 + l31, grp, h);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            float* wa = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
+            tile_store<BM, A_KM>(wa, ra, tid);
+            tile_store<BN, B_KM>(wa + A_TILE, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            if (col >= g.N) continue;
+            float badd = 0.f;
+            if (g.bias) badd += g.bias[col];
+            if (g.bias2) badd += g.bias2[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M) {
+                    float* dst = g.C + (int64_t)row * g.ldc + col;
+                    float v = acc[i][j][r] + badd;
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN>
+int launch(const GemmArgs& g, int a_km, int b_km, hipStream_t st) {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid(tiles), block(256);
+    if (!a_km && !b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
+    else if (!a_km && b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
+    else if (a_km && !b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, st, g);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+}  // namespace
+
+extern "C" int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
+                             const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
+                             int M, int N, int K, const float* bias, const float* bias2,
+                             int accumulate, icrl_stream_t stream) {
+    ICRL_REQUIRE(A && B && C, "icrl_gemm_f32: null operand");
+    ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "icrl_gemm_f32: empty shape %dx%dx%d", M, N, K);
+    ICRL_REQUIRE(!(a_rows && a_kmajor), "icrl_gemm_f32: row gather needs a_kmajor = 0");
+    ICRL_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N,
+                 "icrl_gemm_f32: leading dimension smaller than the row length");
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.a_rows = a_rows; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.bias2 = bias2; g.accumulate = accumulate;
+    g.a_vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
+    g.b_vec = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
+    const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    if (big_tiles >= 256) return launch<128, 128>(g, a_kmajor, b_kmajor, icrl::as_stream(stream));
+    return launch<64, 64>(g, a_kmajor, b_kmajor, icrl::as_stream(stream));
+}

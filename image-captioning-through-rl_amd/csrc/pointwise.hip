@@ -1,0 +1,388 @@
+// Memory-bound kernels of the A2C step: embedding gather / scatter-add, bias-gradient
+// column sums, the batched LSTM cell, value head finish, cosine reward, the
+// advantage / policy-gradient loss, d-logits and Adam.  All are HBM-bound: 16-byte
+// accesses per lane, grid capped at ~2048 workgroups with grid-stride loops.
+#include "icrl_common.h"
+
+namespace {
+using namespace icrl;
+
+constexpr int H = kHidden;
+
+inline int grid_for(int64_t work_items, int block) {
+    int64_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- gather / scatter
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, int width,
+                                                          const int64_t* __restrict__ idx,
+                                                          int64_t idx_stride, int rows,
+                                                          float* __restrict__ out) {
+    const int w4 = width >> 2;
+    const int64_t total = (int64_t)rows * w4;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / w4), c = (int)(e % w4);
+        const int64_t src = idx[r * idx_stride];
+        reinterpret_cast<float4*>(out)[e] = reinterpret_cast<const float4*>(table + src * width)[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict__ grad, int width,
+                                                               const int64_t* __restrict__ idx,
+                                                               int64_t idx_stride, int rows,
+                                                               const float* __restrict__ in) {
+    // one wave-instruction adds 256 contiguous bytes of one destination row
+    const int64_t total = (int64_t)rows * width;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / width), c = (int)(e % width);
+        const int64_t dst = idx[r * idx_stride];
+        atomicAdd(grad + dst * width + c, in[e]);
+    }
+}
+
+// out[n] (+)= sum_r x[r, n]; one workgroup per 64 columns, 4 waves stride the rows.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
+                                                     int cols, float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (col < cols)
+        for (int r = wave; r < rows; r += 4) s += x[(int64_t)r * ldx + col];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        const float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
+// ---------------------------------------------------------------- batched LSTM cell
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ gates,
+                                                            const float* __restrict__ c_prev,
+                                                            float* __restrict__ c_out,
+                                                            float* __restrict__ h_out, int n) {
+    const int64_t total = (int64_t)n * (H / 4);
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int row = (int)(e / (H / 4)), j4 = (int)(e % (H / 4));
+        float4* g = reinterpret_cast<float4*>(gates + (int64_t)row * 4 * H);
+        float4 gi = g[j4], gf = g[H / 4 + j4], gg = g[2 * (H / 4) + j4], go = g[3 * (H / 4) + j4];
+        const float4 cp = reinterpret_cast<const float4*>(c_prev)[e];
+        float4 c, h;
+#define ICRL_CELL(k)                                            \
+    gi.k = sigmoidf_(gi.k); gf.k = sigmoidf_(gf.k);             \
+    gg.k = tanhf_(gg.k);   go.k = sigmoidf_(go.k);              \
+    c.k = gf.k * cp.k + gi.k * gg.k;                            \
+    h.k = go.k * tanhf_(c.k);
+        ICRL_CELL(x) ICRL_CELL(y) ICRL_CELL(z) ICRL_CELL(w)
+#undef ICRL_CELL
+        g[j4] = gi; g[H / 4 + j4] = gf; g[2 * (H / 4) + j4] = gg; g[3 * (H / 4) + j4] = go;
+        reinterpret_cast<float4*>(c_out)[e] = c;
+        reinterpret_cast<float4*>(h_out)[e] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates,
+                                                            const float* __restrict__ c_prev,
+                                                            const float* __restrict__ c,
+                                                            const float* __restrict__ dh,
+                                                            const float* __restrict__ dc_in,
+                                                            float* __restrict__ dgates,
+                                                            float* __restrict__ dc_prev, int n) {
+    const int64_t total = (int64_t)n * H;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int row = (int)(e / H), j = (int)(e % H);
+        const float* g = gates + (int64_t)row * 4 * H;
+        const float i = g[j], f = g[H + j], gg = g[2 * H + j], o = g[3 * H + j];
+        const float tc = tanhf_(c[e]);
+        const float dhv = dh[e];
+        float dcv = dhv * o * (1.f - tc * tc);
+        if (dc_in) dcv += dc_in[e];
+        float* d = dgates + (int64_t)row * 4 * H;
+        d[j] = dcv * gg * i * (1.f - i);
+        d[H + j] = dcv * c_prev[e] * f * (1.f - f);
+        d[2 * H + j] = dcv * i * (1.f - gg * gg);
+        d[3 * H + j] = dhv * tc * o * (1.f - o);
+        dc_prev[e] = dcv * f;
+    }
+}
+
+// ---------------------------------------------------------------- value head finish
+// one wave per row: y = yh + u[row % N]; value = y.w2 + b2
+__global__ __launch_bounds__(256) void value_head_kernel(float* __restrict__ yh, const float* __restrict__ u,
+                                                         const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, int rows, int n,
+                                                         float* __restrict__ values) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        float4* y = reinterpret_cast<float4*>(yh + (int64_t)row * 512);
+        const float4* uu = reinterpret_cast<const float4*>(u + (int64_t)(row % n) * 512);
+        const float4* w = reinterpret_cast<const float4*>(w2);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float4 a = y[lane + 64 * k];
+            const float4 b = uu[lane + 64 * k], ww = w[lane + 64 * k];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            y[lane + 64 * k] = a;
+            s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) values[row] = s + b2[0];
+    }
+}
+
+// ---------------------------------------------------------------- cosine reward
+__global__ __launch_bounds__(256) void cosine_reward_kernel(const float* __restrict__ ve,
+                                                            const float* __restrict__ se, int rows, int n,
+                                                            float* __restrict__ reward) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const float4* a = reinterpret_cast<const float4*>(ve + (int64_t)(row % n) * 512);
+        const float4* b = reinterpret_cast<const float4*>(se + (int64_t)row * 512);
+        float aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float4 x = a[lane + 64 * k], y = b[lane + 64 * k];
+            aa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            bb += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+            ab += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        aa = wave_sum(aa); bb = wave_sum(bb); ab = wave_sum(ab);
+        if (lane == 0) {
+            const float na = fmaxf(sqrtf(aa), 1e-12f), nb = fmaxf(sqrtf(bb), 1e-12f);
+            reward[row] = ab / (na * nb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- A2C loss
+// Single workgroup (count is N*(L-1) <= a few 10^4): double accumulation of the sums.
+__global__ __launch_bounds__(1024) void a2c_loss_kernel(const float* __restrict__ values,
+                                                        const float* __restrict__ rewards,
+                                                        const float* __restrict__ logp, int count,
+                                                        float* __restrict__ scalars,
+                                                        float* __restrict__ d_value,
+                                                        float* __restrict__ d_logp) {
+    __shared__ double red[16][4];
+    const float inv = 1.0f / (float)count;
+    double s_act = 0., s_cri = 0., s_rew = 0., s_adv = 0.;
+    for (int e = threadIdx.x; e < count; e += 1024) {
+        const float v = values[e], r = rewards[e], lp = logp[e];
+        const float adv = v - r;
+        s_act += (double)(-lp * adv);
+        s_cri += (double)(adv * adv);
+        s_rew += (double)r;
+        s_adv += (double)adv;
+        if (d_value) d_value[e] = (adv - lp) * inv;
+        if (d_logp) d_logp[e] = -adv * inv;
+    }
+    s_act = wave_sum_d(s_act); s_cri = wave_sum_d(s_cri);
+    s_rew = wave_sum_d(s_rew); s_adv = wave_sum_d(s_adv);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = s_act; red[wave][1] = s_cri; red[wave][2] = s_rew; red[wave][3] = s_adv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0., c = 0., r = 0., d = 0.;
+        for (int w = 0; w < 16; ++w) { a += red[w][0]; c += red[w][1]; r += red[w][2]; d += red[w][3]; }
+        const double actor = a / count, critic = 0.5 * c / count;
+        scalars[0] = (float)(actor + critic);
+        scalars[1] = (float)actor;
+        scalars[2] = (float)critic;
+        scalars[3] = (float)(r / count);
+        scalars[4] = (float)(d / count);
+    }
+}
+
+// g[r,k] = coef[r] * (onehot(token[r])[k] - p[r,k]), in place over p
+__global__ __launch_bounds__(256) void policy_dlogits_kernel(float* __restrict__ p, int rows, int V,
+                                                             const int64_t* __restrict__ tokens,
+                                                             int64_t token_stride,
+                                                             const float* __restrict__ coef) {
+    const int64_t total = (int64_t)rows * V;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / V), k = (int)(e % V);
+        const float c = coef[r];
+        const float hot = (tokens[r * token_stride] == (int64_t)k) ? 1.f : 0.f;
+        p[e] = c * (hot - p[e]);
+    }
+}
+
+// ---------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr, float b1, float b2, float eps, float bc1,
+                                                   float bc2_sqrt) {
+    // torch.optim.Adam: denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
+    const float step_size = lr / bc1;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float gv = g[e];
+        const float mv = b1 * m[e] + (1.f - b1) * gv;
+        const float vv = b2 * v[e] + (1.f - b2) * gv * gv;
+        m[e] = mv; v[e] = vv;
+        p[e] -= step_size * mv / (sqrtf(vv) / bc2_sqrt + eps);
+    }
+}
+
+// ---------------------------------------------------------------- chain helpers
+// out[(t*N+i), :] = sum_{s : p0+s > t} dgates[off(s) + t*N + i, :], off(s) = N*sum_{s'<s}(p0+s')
+__global__ __launch_bounds__(256) void chain_fold_kernel(const float* __restrict__ dg, int n, int p0,
+                                                         int n_calls, int w4, float4* __restrict__ out) {
+    const int cols = p0 + n_calls - 1;
+    const int64_t total = (int64_t)cols * n * w4;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t rowi = e / w4;  // t*N + i
+        const int c = (int)(e % w4);
+        const int t = (int)(rowi / n);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t off = 0;
+        for (int call = 0; call < n_calls; ++call) {
+            const int len = p0 + call;
+            if (t < len) {
+                const float4 v = reinterpret_cast<const float4*>(dg)[(off + rowi) * w4 + c];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            off += (int64_t)len * n;
+        }
+        out[e] = s;
+    }
+}
+
+// h_prev[pos,:] = saved[pos-1, 5H:6H] (zeros at pos 0)
+__global__ __launch_bounds__(256) void chain_hprev_kernel(const float* __restrict__ saved, int64_t positions,
+                                                          float4* __restrict__ h_prev) {
+    const int64_t total = positions * (H / 4);
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t pos = e / (H / 4);
+        const int c = (int)(e % (H / 4));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pos > 0) v = reinterpret_cast<const float4*>(saved + (pos - 1) * 6 * H + 5 * H)[c];
+        h_prev[e] = v;
+    }
+}
+
+}  // namespace
+
+using icrl::as_stream;
+
+extern "C" int icrl_gather_rows(const float* table, int width, const int64_t* idx, int64_t idx_stride,
+                                int rows, float* out, icrl_stream_t stream) {
+    ICRL_REQUIRE(table && idx && out && rows > 0, "icrl_gather_rows: null pointer or no rows");
+    ICRL_REQUIRE(width % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(out) % 16 == 0, "icrl_gather_rows: width %% 4 and 16-byte alignment required");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)rows * width / 4, 256)), dim3(256), 0,
+                       as_stream(stream), table, width, idx, idx_stride, rows, out);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_scatter_add_rows(float* grad_table, int width, const int64_t* idx, int64_t idx_stride,
+                                     int rows, const float* rows_in, icrl_stream_t stream) {
+    ICRL_REQUIRE(grad_table && idx && rows_in && rows > 0, "icrl_scatter_add_rows: null pointer or no rows");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((int64_t)rows * width, 256)), dim3(256), 0,
+                       as_stream(stream), grad_table, width, idx, idx_stride, rows, rows_in);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
+                           icrl_stream_t stream) {
+    ICRL_REQUIRE(x && out && rows > 0 && cols > 0, "icrl_colsum: null pointer or empty shape");
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), x, ldx, rows,
+                       cols, out, accumulate);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_lstm_cell_fwd(float* gates, const float* c_prev, float* c, float* h, int N,
+                                  icrl_stream_t stream) {
+    ICRL_REQUIRE(gates && c_prev && c && h && N > 0, "icrl_lstm_cell_fwd: null pointer or N <= 0");
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((int64_t)N * H / 4, 256)), dim3(256), 0,
+                       as_stream(stream), gates, c_prev, c, h, N);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c,
+                                  const float* dh, const float* dc, float* dgates, float* dc_prev, int N,
+                                  icrl_stream_t stream) {
+    ICRL_REQUIRE(gates_act && c_prev && c && dh && dgates && dc_prev && N > 0,
+                 "icrl_lstm_cell_bwd: null pointer or N <= 0");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((int64_t)N * H, 256)), dim3(256), 0,
+                       as_stream(stream), gates_act, c_prev, c, dh, dc, dgates, dc_prev, N);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_value_head_fwd(float* yh_inout, const float* u, const float* w2, const float* b2,
+                                   int rows, int N, float* values, icrl_stream_t stream) {
+    ICRL_REQUIRE(yh_inout && u && w2 && b2 && values && rows > 0 && N > 0,
+                 "icrl_value_head_fwd: null pointer or empty shape");
+    hipLaunchKernelGGL(value_head_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, as_stream(stream), yh_inout,
+                       u, w2, b2, rows, N, values);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_cosine_reward(const float* ve, const float* se, int rows, int N, float* reward,
+                                  icrl_stream_t stream) {
+    ICRL_REQUIRE(ve && se && reward && rows > 0 && N > 0, "icrl_cosine_reward: null pointer or empty shape");
+    hipLaunchKernelGGL(cosine_reward_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, as_stream(stream), ve, se,
+                       rows, N, reward);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_a2c_loss(const float* values, const float* rewards, const float* log_probs, int count,
+                             float* scalars, float* d_value, float* d_logp, icrl_stream_t stream) {
+    ICRL_REQUIRE(values && rewards && log_probs && scalars && count > 0,
+                 "icrl_a2c_loss: null pointer or count <= 0");
+    hipLaunchKernelGGL(a2c_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), values, rewards, log_probs,
+                       count, scalars, d_value, d_logp);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_policy_dlogits(float* probs_inout, int rows, int V, const int64_t* tokens,
+                                   int64_t token_stride, const float* coef, icrl_stream_t stream) {
+    ICRL_REQUIRE(probs_inout && tokens && coef && rows > 0 && V > 0,
+                 "icrl_policy_dlogits: null pointer or empty shape");
+    hipLaunchKernelGGL(policy_dlogits_kernel, dim3(grid_for((int64_t)rows * V, 256)), dim3(256), 0,
+                       as_stream(stream), probs_inout, rows, V, tokens, token_stride, coef);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              float lr, float beta1, float beta2, float eps, int step,
+                              icrl_stream_t stream) {
+    ICRL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0,
+                 "icrl_adam_step: null pointer, n <= 0 or step <= 0");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
+                                     icrl_stream_t stream) {
+    ICRL_REQUIRE(dgates && out && N > 0 && p0 > 0 && n_calls > 0 && width % 4 == 0,
+                 "icrl_chain_fold_calls: bad argument");
+    const int64_t total = (int64_t)(p0 + n_calls - 1) * N * (width / 4);
+    hipLaunchKernelGGL(chain_fold_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), dgates, N,
+                       p0, n_calls, width / 4, reinterpret_cast<float4*>(out));
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_chain_hprev(const float* saved, int64_t positions, float* h_prev, icrl_stream_t stream) {
+    ICRL_REQUIRE(saved && h_prev && positions > 0, "icrl_chain_hprev: bad argument");
+    hipLaunchKernelGGL(chain_hprev_kernel, dim3(grid_for(positions * (H / 4), 256)), dim3(256), 0,
+                       as_stream(stream), saved, positions, reinterpret_cast<float4*>(h_prev));
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}

@@ -1,0 +1,177 @@
+// Batched autoregressive sampler: one 256-thread workgroup per row of logits[N,V].
+//
+// Sampling reproduces numpy.random.choice(V, p=softmax(logits)) for an externally
+// supplied uniform u: the probabilities are float32 (the reference copies a float32
+// softmax to the host), the CDF is accumulated in float64 and divided by its last entry,
+// and the token is the number of CDF entries <= u (searchsorted side="right").
+// The row lives in LDS (V*4 bytes) between the passes; the float64 prefix sums are
+// built from per-thread contiguous chunks + a wavefront scan (64-lane __shfl_up) +
+// a 4-entry cross-wave scan.
+#include "icrl_common.h"
+
+namespace {
+using namespace icrl;
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int64_t ld, int V,
+                                                     const double* __restrict__ uniforms,
+                                                     int64_t* __restrict__ tokens, int64_t token_stride,
+                                                     float* __restrict__ log_prob, int64_t lp_stride,
+                                                     float* __restrict__ probs, float* __restrict__ entropy) {
+    extern __shared__ __attribute__((aligned(16))) float row[];  // V floats
+    __shared__ float redf[4];
+    __shared__ double redd[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    const float* src = logits + (int64_t)r * ld;
+
+    if (MODE == ICRL_GREEDY) {
+        // argmax, first index wins on ties (torch.argmax on a CPU/GPU tensor row)
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = tid; k < V; k += 256) {
+            const float v = src[k];
+            if (v > best) { best = v; bi = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
+            tokens[r * token_stride] = (int64_t)bi;
+            if (log_prob) log_prob[r * lp_stride] = 0.f;
+        }
+        return;
+    }
+
+    // pass 1: row -> LDS, maximum
+    float m = -INFINITY;
+    for (int k = tid; k < V; k += 256) {
+        const float v = src[k];
+        row[k] = v;
+        m = fmaxf(m, v);
+    }
+    m = block_max(m, redf);
+    // pass 2: exponentials, their float32 sum
+    float s = 0.f;
+    for (int k = tid; k < V; k += 256) {
+        const float e = expf(row[k] - m);
+        row[k] = e;
+        s += e;
+    }
+    s = block_sum(s, redf);
+    // pass 3: probabilities (float32 division, as torch's softmax does), optional outputs
+    float ent = 0.f;
+    for (int k = tid; k < V; k += 256) {
+        const float p = row[k] / s;
+        row[k] = p;
+        if (probs) probs[(int64_t)r * V + k] = p;
+        if (entropy && p > 0.f) ent -= p * logf(p);
+    }
+    if (entropy) {
+        ent = block_sum(ent, redf);
+        if (tid == 0) entropy[r] = ent;
+    }
+    __syncthreads();
+
+    int token;
+    if (MODE == ICRL_SAMPLE) {
+        const int chunk = (V + 255) / 256;
+        const int k0 = tid * chunk, k1 = min(k0 + chunk, V);
+        double local = 0.;
+        for (int k = k0; k < k1; ++k) local += (double)row[k];
+        // inclusive scan over the 256 chunk sums
+        double inc = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) redd[wave] = inc;
+        __syncthreads();
+        double wave_off = 0., total = 0.;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wave_off += redd[w];
+            total += redd[w];
+        }
+        double running = wave_off + inc - local;  // exclusive prefix of this chunk
+        const double u = uniforms[r];
+        int cnt = 0;
+        for (int k = k0; k < k1; ++k) {
+            running += (double)row[k];
+            cnt += (running / total <= u) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) redi[wave] = cnt;
+        __syncthreads();
+        token = redi[0] + redi[1] + redi[2] + redi[3];
+        if (token > V - 1) token = V - 1;
+        if (tid == 0) tokens[r * token_stride] = (int64_t)token;
+    } else {
+        token = (int)tokens[r * token_stride];
+    }
+    if (tid == 0 && log_prob) {
+        const bool ok = token >= 0 && token < V;
+        log_prob[r * lp_stride] = ok ? logf(row[token]) : NAN;
+    }
+}
+
+}  // namespace
+
+extern "C" int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int mode,
+                                  const double* uniforms, int64_t* tokens_out, int64_t token_stride,
+                                  float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
+                                  icrl_stream_t stream) {
+    ICRL_REQUIRE(logits && tokens_out && N > 0 && V > 0, "icrl_sample_tokens: null pointer or empty shape");
+    ICRL_REQUIRE(ld_logits >= V, "icrl_sample_tokens: ld_logits < V");
+    ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_sample_tokens: vocabulary %d exceeds the 16384-entry LDS row", V);
+    ICRL_REQUIRE(mode != ICRL_SAMPLE || uniforms, "icrl_sample_tokens: ICRL_SAMPLE needs uniforms");
+    hipStream_t st = icrl::as_stream(stream);
+    const size_t lds = (size_t)V * sizeof(float);
+    dim3 grid(N), block(256);
+    switch (mode) {
+        case ICRL_SAMPLE:
+            hipLaunchKernelGGL(sample_kernel<ICRL_SAMPLE>, grid, block, lds, st, logits, ld_logits, V, uniforms,
+                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy);
+            break;
+        case ICRL_GREEDY:
+            hipLaunchKernelGGL(sample_kernel<ICRL_GREEDY>, grid, block, 0, st, logits, ld_logits, V, uniforms,
+                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy);
+            break;
+        case ICRL_FORCED:
+            hipLaunchKernelGGL(sample_kernel<ICRL_FORCED>, grid, block, lds, st, logits, ld_logits, V, uniforms,
+                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy);
+            break;
+        default:
+            icrl::set_error("icrl_sample_tokens: unknown mode %d", mode);
+            return ICRL_ERR_ARG;
+    }
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}

@@ -1,0 +1,224 @@
+"""ctypes binding of libicrl_a2c.so (the C ABI declared in include/icrl_a2c.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``.
+There is no CPU fallback: if the shared object is missing, every call raises.
+Tensors cross the boundary as raw device pointers (``tensor.data_ptr()``) plus the
+current HIP stream; PyTorch only owns the memory.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicrl_a2c.so")
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/icrl_a2c.h one to one
+SIGNATURES = {
+    "icrl_abi_version": (c_int, []),
+    "icrl_last_error": (ctypes.c_char_p, []),
+    "icrl_gemm_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int,
+                              c_vp, c_vp, c_int, c_vp]),
+    "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
+    "icrl_lstm_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                   c_vp]),
+    "icrl_policy_dlogits": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "icrl_chain_sync_bytes": (c_i64, []),
+    "icrl_lstm_chain_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_lstm_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_chain_fold_calls": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "icrl_chain_hprev": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "icrl_value_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "icrl_cosine_reward": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "icrl_a2c_loss": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
+}
+
+SAMPLE, GREEDY, FORCED = 0, 1, 2
+ABI_VERSION = 1
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the A2C kernels)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.icrl_abi_version() != ABI_VERSION:
+        raise HipExtensionMissing("libicrl_a2c.so has ABI %d, bindings expect %d; rebuild it"
+                                  % (lib.icrl_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda, "the HIP kernels take device tensors"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().icrl_last_error().decode()))
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, bias2=None, accumulate=False,
+         m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
+    """out[M,N] (+)= A[M,K] @ B[K,N] (+ bias + bias2).
+
+    a: stored [M, K] (a_kmajor False) or [K, M] (True); b: stored [N, K] (False, an
+    nn.Linear weight) or [K, N] (True).  2-D tensors whose last dimension is contiguous;
+    row strides become the leading dimensions, so column slices work."""
+    assert a.dtype == b.dtype == out.dtype == torch.float32
+    assert a.stride(-1) == 1 and b.stride(-1) == 1 and out.stride(-1) == 1
+    if m is None:
+        m = a.shape[1] if a_kmajor else (a_rows.numel() if a_rows is not None else a.shape[0])
+    if k is None:
+        k = a.shape[0] if a_kmajor else a.shape[1]
+    if n is None:
+        n = b.shape[1] if b_kmajor else b.shape[0]
+    assert (b.shape[0] if b_kmajor else b.shape[1]) == k, (tuple(a.shape), tuple(b.shape))
+    assert out.shape[0] == m and out.shape[1] == n, (tuple(out.shape), m, n)
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    if a_rows is not None:
+        assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
+    rc = load().icrl_gemm_f32(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor), _ptr(out),
+                              ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), _stream())
+    _check(rc, "icrl_gemm_f32")
+    return out
+
+
+def gather_rows(table, idx, idx_stride, rows, out):
+    _check(load().icrl_gather_rows(_ptr(_f32c(table)), table.shape[1], _ptr(idx), idx_stride, rows, _ptr(out),
+                                   _stream()), "icrl_gather_rows")
+    return out
+
+
+def scatter_add_rows(grad_table, idx, idx_stride, rows, rows_in):
+    _check(load().icrl_scatter_add_rows(_ptr(_f32c(grad_table)), grad_table.shape[1], _ptr(idx), idx_stride, rows,
+                                        _ptr(_f32c(rows_in)), _stream()), "icrl_scatter_add_rows")
+
+
+def colsum(x, out, accumulate=False, rows=None):
+    rows = x.shape[0] if rows is None else rows
+    _check(load().icrl_colsum(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(out), int(accumulate), _stream()),
+           "icrl_colsum")
+    return out
+
+
+def lstm_cell_fwd(gates, c_prev, c, h):
+    _check(load().icrl_lstm_cell_fwd(_ptr(_f32c(gates)), _ptr(_f32c(c_prev)), _ptr(_f32c(c)), _ptr(_f32c(h)),
+                                     gates.shape[0], _stream()), "icrl_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(gates_act, c_prev, c, dh, dc, dgates, dc_prev):
+    _check(load().icrl_lstm_cell_bwd(_ptr(_f32c(gates_act)), _ptr(_f32c(c_prev)), _ptr(_f32c(c)), _ptr(_f32c(dh)),
+                                     _ptr(dc), _ptr(_f32c(dgates)), _ptr(_f32c(dc_prev)), gates_act.shape[0],
+                                     _stream()), "icrl_lstm_cell_bwd")
+
+
+def sample_tokens(logits, mode, tokens_out, token_stride, *, uniforms=None, log_prob=None, log_prob_stride=1,
+                  probs=None, entropy=None):
+    n, v = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    assert tokens_out.dtype == torch.int64
+    if uniforms is not None:
+        assert uniforms.dtype == torch.float64 and uniforms.is_contiguous() and uniforms.numel() >= n
+    _check(load().icrl_sample_tokens(_ptr(logits), logits.stride(0), n, v, mode, _ptr(uniforms), _ptr(tokens_out),
+                                     token_stride, _ptr(log_prob), log_prob_stride, _ptr(probs), _ptr(entropy),
+                                     _stream()), "icrl_sample_tokens")
+
+
+def policy_dlogits(probs_inout, tokens, token_stride, coef):
+    rows, v = probs_inout.shape
+    _check(load().icrl_policy_dlogits(_ptr(_f32c(probs_inout)), rows, v, _ptr(tokens), token_stride,
+                                      _ptr(_f32c(coef)), _stream()), "icrl_policy_dlogits")
+
+
+def chain_sync_bytes():
+    return int(load().icrl_chain_sync_bytes())
+
+
+def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, state_in=None, state_out=None):
+    """p0 = caption columns seen by the first call; call s covers p0 + s columns."""
+    _check(load().icrl_lstm_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, _ptr(_f32c(h_emit)),
+                                      _ptr(saved), _ptr(state_in), _ptr(state_out), _ptr(sync_ws), _ptr(status),
+                                      _stream()), "icrl_lstm_chain_fwd")
+
+
+def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, state_in=None, state_out=None):
+    _check(load().icrl_gru_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
+                                     _ptr(_f32c(h_emit)), _ptr(state_in), _ptr(state_out), _ptr(sync_ws),
+                                     _ptr(status), _stream()), "icrl_gru_chain_fwd")
+
+
+def lstm_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates, sync_ws, status):
+    _check(load().icrl_lstm_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
+                                      _ptr(_f32c(dgates)), _ptr(sync_ws), _ptr(status), _stream()),
+           "icrl_lstm_chain_bwd")
+
+
+def chain_fold_calls(dgates, n, p0, n_calls, width, out):
+    _check(load().icrl_chain_fold_calls(_ptr(_f32c(dgates)), n, p0, n_calls, width, _ptr(_f32c(out)), _stream()),
+           "icrl_chain_fold_calls")
+
+
+def chain_hprev(saved, positions, h_prev):
+    _check(load().icrl_chain_hprev(_ptr(_f32c(saved)), positions, _ptr(_f32c(h_prev)), _stream()),
+           "icrl_chain_hprev")
+
+
+def value_head_fwd(yh_inout, u, w2, b2, rows, n, values):
+    _check(load().icrl_value_head_fwd(_ptr(_f32c(yh_inout)), _ptr(_f32c(u)), _ptr(_f32c(w2)), _ptr(_f32c(b2)), rows,
+                                      n, _ptr(_f32c(values)), _stream()), "icrl_value_head_fwd")
+
+
+def cosine_reward(ve, se, rows, n, reward):
+    _check(load().icrl_cosine_reward(_ptr(_f32c(ve)), _ptr(_f32c(se)), rows, n, _ptr(_f32c(reward)), _stream()),
+           "icrl_cosine_reward")
+
+
+def a2c_loss(values, rewards, log_probs, scalars, d_value=None, d_logp=None):
+    _check(load().icrl_a2c_loss(_ptr(_f32c(values)), _ptr(_f32c(rewards)), _ptr(_f32c(log_probs)), values.numel(),
+                                _ptr(_f32c(scalars)), _ptr(d_value), _ptr(d_logp), _stream()), "icrl_a2c_loss")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    _check(load().icrl_adam_step(_ptr(_f32c(param)), _ptr(_f32c(grad)), _ptr(_f32c(exp_avg)),
+                                 _ptr(_f32c(exp_avg_sq)), param.numel(), lr, beta1, beta2, eps, step, _stream()),
+           "icrl_adam_step")

@@ -1,0 +1,170 @@
+/*
+ * C ABI of libicrl_a2c.so: hand-written gfx950 (MI355X) HIP kernels for the
+ * Advantage-Actor-Critic caption-training step.
+ *
+ * The reference (pratikpv/image-captioning-through-rl) is pure Python/PyTorch and
+ * has no FFI of its own; each entry point below replaces the PyTorch calls at the
+ * cited reference file:line.  Conventions:
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - buffers, including workspaces, are owned by the caller; nothing here
+ *     allocates or frees device memory;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - return value: 0 on success, negative ICRL_ERR_* otherwise, with a message
+ *     available from icrl_last_error() (per host thread).  No exceptions cross
+ *     the boundary;
+ *   - one host thread per GPU; matrices are row-major float32, token ids int64;
+ *   - H = 512 is the hidden width of every recurrent layer (models.py:41, 94, 189).
+ */
+#ifndef ICRL_A2C_H
+#define ICRL_A2C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* icrl_stream_t;
+
+#define ICRL_OK 0
+#define ICRL_ERR_ARG (-1)     /* bad shape, alignment or null pointer */
+#define ICRL_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define ICRL_ERR_TIMEOUT (-3) /* a chain kernel gave up waiting for a peer workgroup */
+
+#define ICRL_ABI_VERSION 1
+
+int icrl_abi_version(void);
+const char* icrl_last_error(void);
+
+/* ---- dense contraction -------------------------------------------------------
+ * C[M,N] = (accumulate ? C : 0) + A[M,K] * B[K,N] + bias[n] + bias2[n]
+ * on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces every nn.Linear and
+ * the LSTM's gate products on the path: models.py:75 (cnn2linear), :80 (lstm),
+ * :82 (linear2vocab), :177-178 (value head), :259-260 (reward embeds) and their
+ * autograd transposes (trainers.py:479).
+ *   a_kmajor = 0: A stored [M][lda] (k contiguous); 1: stored [K][lda] (m contiguous)
+ *   b_kmajor = 0: B stored [N][ldb] (k contiguous, an nn.Linear weight); 1: [K][ldb]
+ *   a_rows: optional int64[M] row gather for A (a_kmajor = 0 only), i.e. the
+ *           nn.Embedding lookup of models.py:73 fused into the product.
+ *   bias, bias2: optional float[N]. */
+int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
+                  const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
+                  int M, int N, int K, const float* bias, const float* bias2,
+                  int accumulate, icrl_stream_t stream);
+
+/* out[r, :] = table[idx[r*idx_stride], :]   (nn.Embedding, models.py:73, 132, 225) */
+int icrl_gather_rows(const float* table, int width, const int64_t* idx, int64_t idx_stride,
+                     int rows, float* out, icrl_stream_t stream);
+
+/* grad_table[idx[r*idx_stride], :] += rows_in[r, :]  (Embedding backward, float atomics) */
+int icrl_scatter_add_rows(float* grad_table, int width, const int64_t* idx, int64_t idx_stride,
+                          int rows, const float* rows_in, icrl_stream_t stream);
+
+/* out[n] (+)= sum_r x[r, n]   (bias gradients) */
+int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
+                icrl_stream_t stream);
+
+/* ---- batched LSTM cell (policy network, models.py:80) -----------------------
+ * gates_pre[N,4H] holds x*W_ih^T + h*W_hh^T + b_ih + b_hh, PyTorch order i,f,g,o.
+ * fwd: c = sig(f)*c_prev + sig(i)*tanh(g); h = sig(o)*tanh(c); the activated
+ *      gates are written back over gates_pre for the backward pass.
+ * bwd: given dh, dc (dc may be null = 0) and the saved activations, writes
+ *      dgates[N,4H] (w.r.t. the pre-activations) and dc_prev. */
+int icrl_lstm_cell_fwd(float* gates, const float* c_prev, float* c, float* h, int N,
+                       icrl_stream_t stream);
+int icrl_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c,
+                       const float* dh, const float* dc, float* dgates, float* dc_prev, int N,
+                       icrl_stream_t stream);
+
+/* ---- batched autoregressive sampler (trainers.py:444-458, :69) ---------------
+ * One workgroup per row of logits[N,V]:
+ *   mode ICRL_SAMPLE: softmax in f32, float64 CDF, token = #{k : cdf[k]/cdf[V-1] <= u}
+ *        with ONE uniform double per row - numpy.random.choice(V, p=...) given the
+ *        same draw; log_prob = log(p[token]).
+ *   mode ICRL_GREEDY: token = argmax logits, first index wins (torch.argmax).
+ *   mode ICRL_FORCED: token is read from tokens_out; only log_prob is produced.
+ * tokens_out[i*token_stride] receives / holds the int64 token.  probs (optional,
+ * [N,V]) receives the softmax; entropy (optional, [N]) the diagnostic
+ * -sum p log p, which the reference's loss does NOT contain. */
+#define ICRL_SAMPLE 0
+#define ICRL_GREEDY 1
+#define ICRL_FORCED 2
+int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int mode,
+                       const double* uniforms, int64_t* tokens_out, int64_t token_stride,
+                       float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
+                       icrl_stream_t stream);
+
+/* d logits for the policy-gradient term, in place over the saved softmax:
+ * g[r, k] = coef[r] * ((k == token[r]) - p[r, k]),  coef = dLoss/dlog_prob. */
+int icrl_policy_dlogits(float* probs_inout, int rows, int V, const int64_t* tokens,
+                        int64_t token_stride, const float* coef, icrl_stream_t stream);
+
+/* ---- batch-1 recurrent chains (models.py:130-135, 166-169; :223-228, 253-255) -
+ * The reference feeds (N,1,E) to an nn.LSTM / nn.GRU built without batch_first,
+ * so the N rows of a minibatch are consecutive time steps of ONE recurrence whose
+ * state also carries across columns and across successive forward() calls.
+ * Position order: for call s in [0, n_calls): for column t in [0, p0+s):
+ * for row i in [0, N); p0 is the number of caption columns the FIRST call sees (the
+ * reward network also sees the newly sampled token, trainers.py:454-459, so its caller
+ * passes one more than the value network's).  xproj[(t*N + i), G*H] holds
+ * W_ih*emb[token[i,t]] + b_ih
+ * (+ b_hh for the LSTM), G = 4 (LSTM, gates i,f,g,o) or 3 (GRU, gates r,z,n).
+ * The kernel is persistent: ICRL_CHAIN_WGS workgroups each keep a slice of W_hh in
+ * registers and exchange the 512-float state once per step through tagged 8-byte
+ * granules in `sync_ws` (icrl_chain_sync_bytes(), zeroed by the call itself).
+ * h_emit[s, i, :] receives the hidden output at the last column of call s.
+ * For the LSTM, `saved` (optional) receives per position {i,f,g,o,c,h} = 6*H floats
+ * for the backward pass.  state_in (optional, {h, c} = 2*H floats, GRU: h only) is the
+ * carried hidden state (models.py:127-128, 133: hidden_cell survives across forward()
+ * calls until init_hidden()); null = zeros.  state_out (optional) receives the final
+ * state.  status: one int32 the kernel sets non-zero on time-out. */
+#define ICRL_CHAIN_WGS 64
+int64_t icrl_chain_sync_bytes(void);
+int icrl_lstm_chain_fwd(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+                        float* h_emit, float* saved, const float* state_in, float* state_out,
+                        void* sync_ws, int32_t* status, icrl_stream_t stream);
+int icrl_gru_chain_fwd(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
+                       int n_calls, float* h_emit, const float* state_in, float* state_out,
+                       void* sync_ws, int32_t* status, icrl_stream_t stream);
+/* Backward of icrl_lstm_chain_fwd (autograd through models.py:133, trainers.py:479):
+ * walks the positions in reverse; d_emit[s,i,:] is dLoss/dh_emit; writes
+ * dgates[pos, 4H] (gradient w.r.t. every position's gate pre-activations).  The
+ * forward pass must have started from a zero state (as every A2C minibatch does,
+ * trainers.py:495-496). */
+int icrl_lstm_chain_bwd(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                        int n_calls, float* dgates, void* sync_ws, int32_t* status,
+                        icrl_stream_t stream);
+/* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
+int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
+                          icrl_stream_t stream);
+/* h_prev[pos, :] = h of position pos-1 (zeros for pos 0), taken from `saved` */
+int icrl_chain_hprev(const float* saved, int64_t positions, float* h_prev, icrl_stream_t stream);
+
+/* ---- value head (models.py:175-178) ------------------------------------------
+ * y[r,:] = yh[r,:] + u[r % N,:]  (u = W1[:, :F]*feat + b1, yh = W1[:, F:]*h_emit);
+ * value[r] = y[r,:].w2 + b2.  No non-linearity between the two layers. */
+int icrl_value_head_fwd(float* yh_inout, const float* u, const float* w2, const float* b2,
+                        int rows, int N, float* values, icrl_stream_t stream);
+
+/* ---- embedding-cosine reward (trainers.py:116-120) ---------------------------
+ * reward[r] = <ve[r % N]/max(|ve|,1e-12), se[r]/max(|se|,1e-12)>, width 512. */
+int icrl_cosine_reward(const float* ve, const float* se, int rows, int N, float* reward,
+                       icrl_stream_t stream);
+
+/* ---- advantage / policy-gradient loss (trainers.py:471-476) -------------------
+ * Inputs are [steps*N] in (step,row) order.  advantage = value - reward;
+ * loss = mean(-logp*adv) + 0.5*mean(adv^2).  scalars[0..4] = loss, actor, critic,
+ * mean reward, mean advantage.  d_value and d_logp receive dLoss/dvalue and
+ * dLoss/dlog_prob (the advantage is not detached in the reference). */
+int icrl_a2c_loss(const float* values, const float* rewards, const float* log_probs, int count,
+                  float* scalars, float* d_value, float* d_logp, icrl_stream_t stream);
+
+/* ---- Adam (trainers.py:378, 480): torch.optim.Adam defaults, bias-corrected ---- */
+int icrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int step,
+                   icrl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICRL_A2C_H */
