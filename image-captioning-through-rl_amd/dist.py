@@ -1,0 +1,68 @@
+"""Data-parallel exchange for the A2C step: one process per GPU, one collective per step.
+
+Each rank runs the whole rollout / loss / backward on its own rows (the value and reward
+recurrences run over the rank's local rows only), then the flat float32 gradient buffer of
+policy + value network is summed across ranks and divided by the world size - a single
+all-reduce (RCCL over xGMI with backend "nccl"; gloo on CPU for tests).  Every rank then
+applies the identical Adam update.  This equals `world` independent reference minibatches
+with averaged gradients, not one reference minibatch of world*N rows, because the
+reference's value / reward recurrences chain the rows of a minibatch together
+(models.py:133, 226).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun's env).
+    Returns (rank, world, local_rank); a no-op (0, 1, 0) when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def average_gradients(flat_grad):
+    """In-place mean over ranks of the flat gradient buffer (sum, then divide)."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        flat_grad.div_(w)
+    return flat_grad
+
+
+def broadcast_parameters(flat, src=0):
+    """Make every rank start from rank `src`'s parameters."""
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def max_over_ranks(value, device):
+    """Max of a python float over ranks (bench timing)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_rows(total_rows, rank=None, world=None):
+    """Contiguous, equal row shard [lo, hi) of a global minibatch for this rank."""
+    world = world_size() if world is None else world
+    rank = (dist.get_rank() if world > 1 else 0) if rank is None else rank
+    assert total_rows % world == 0, "global batch must divide evenly so that mean-of-means is the global mean"
+    per = total_rows // world
+    return rank * per, (rank + 1) * per

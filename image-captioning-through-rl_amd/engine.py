@@ -1,0 +1,258 @@
+"""One A2C minibatch (rollout, rewards, loss, gradients) on the HIP kernels.
+
+This is the host-side schedule of the hot path of trainers.py:436-480 (and the
+curriculum variant, trainers.py:547-594).  It is NOT a step-by-step replay of the
+reference's Python loop; it computes the same numbers in a different order:
+
+  1. policy rollout, incremental: the LSTM state is carried from step to step and only
+     the newest position is projected to the vocabulary (the reference reruns the whole
+     prefix and projects every position each step, models.py:71-84, 286);
+  2. once all tokens exist, the value network's batch-1 LSTM recurrence and the reward
+     network's batch-1 GRU recurrence (models.py:133, 226 fed (N,1,E) without
+     batch_first) each run as ONE persistent kernel over every step's prefix, on two
+     HIP streams at once;
+  3. loss (trainers.py:471-475), then the policy BPTT on one stream beside the value
+     chain's BPTT on the other.
+
+All device memory is PyTorch-owned and cached per problem shape; nothing here touches
+the CPU oracle, and every kernel call raises if libicrl_a2c.so is missing.
+"""
+import torch
+
+from . import hipabi as hip
+
+H = 512
+
+
+class A2CStepResult:
+    """Device tensors of one minibatch.  tokens [N, p0+S] int64; log_probs, values,
+    rewards [N, S] float32; scalars[0..4] = loss, actor, critic, mean reward, mean adv."""
+
+    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status):
+        self.tokens, self.log_probs, self.values, self.rewards = tokens, log_probs, values, rewards
+        self.scalars, self.entropy, self.status = scalars, entropy, status
+
+    def check(self):
+        """Synchronises; raises if a chain kernel gave up waiting for a peer workgroup."""
+        st = self.status.cpu()
+        if int(st.abs().sum()) != 0:
+            raise RuntimeError("a persistent chain kernel timed out (status %s)" % st.tolist())
+        return self
+
+
+class A2CEngine:
+    def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
+                 concurrent=True):
+        """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
+        parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
+        missing from the grads dicts (e.g. frozen pretrained embeddings) get no gradient."""
+        self.P, self.V, self.R = policy_params, value_params, reward_params
+        self.gP, self.gV = policy_grads or {}, value_grads or {}
+        self.concurrent = concurrent
+        self._ws = {}
+        self._side = None
+        dev = self.P["cnn2linear.weight"].device
+        self.device = dev
+        self.vocab, self.E = self.P["caption_embedding.weight"].shape
+        self.F = self.P["cnn2linear.weight"].shape[1]
+        assert self.P["cnn2linear.weight"].shape[0] == H
+        assert self.V["linear1.weight"].shape == (512, self.F + H), "value head width != feature_dim + 512"
+        assert self.R["visual_embed.weight"].shape == (512, self.F)
+        for group in (self.P, self.V, self.R):
+            for k, t in group.items():
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), k
+
+    # ------------------------------------------------------------------ workspaces
+    def _buffers(self, n, p0, s):
+        key = (n, p0, s)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev, v, e, f = self.device, self.vocab, self.E, self.F
+        ev, er = self.V["valrnn.caption_embedding.weight"].shape[1], self.R["rewrnn.caption_embedding.weight"].shape[1]
+        t_steps, l_cols, lv = p0 - 1 + s, p0 + s, p0 + s - 1
+        tv = n * sum(p0 + k for k in range(s))
+
+        def f32(*shape):
+            return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        ws = dict(
+            tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev),
+            Hbuf=f32(t_steps + 1, n, H), Cbuf=f32(t_steps + 1, n, H), gates=f32(t_steps, n, 4 * H),
+            X=f32(t_steps, n, e), logits=f32(n, v), probs=f32(s, n, v), logp=f32(s, n), entropy=f32(s, n),
+            Xv=f32(lv * n, ev), XPv=f32(lv * n, 4 * H), hv=f32(s, n, H), saved=f32(tv, 6, H), U=f32(n, 512),
+            Y=f32(s * n, 512), values=f32(s * n),
+            XPr=f32(l_cols * n, 3 * H), hr=f32(s, n, H), se=f32(s * n, 512), ve=f32(n, 512), rewards=f32(s * n),
+            scalars=torch.zeros(8, dtype=torch.float32, device=dev), dvalue=f32(s * n), dlogp=f32(s * n),
+            sync_v=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
+            sync_r=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
+            status=torch.zeros(4, dtype=torch.int32, device=dev),
+            # backward
+            dY=f32(s * n, 512), dYsum=f32(n, 512), d_emit=f32(s, n, H), dgv=f32(tv, 4 * H), hprev=f32(tv, H),
+            dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev),
+            dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
+            dX=f32(t_steps * n, e), tv=tv,
+        )
+        ws["Cbuf"][0].zero_()
+        self._ws[key] = ws
+        return ws
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    # ------------------------------------------------------------------ the step
+    def step(self, features, prefix, n_steps, uniforms=None, forced_tokens=None, mode=hip.SAMPLE, backward=True):
+        """features [N,F] float32 cuda; prefix [N,p0] int64 cuda (ground-truth start
+        columns: captions[:, :1] for plain A2C, captions[:, :caplen-level] for the
+        curriculum); uniforms: float64 cuda [n_steps*N], one draw per (step,row) in that
+        order, required for mode SAMPLE; forced_tokens [N,p0+n_steps] for mode FORCED."""
+        n, p0 = prefix.shape
+        s = int(n_steps)
+        assert s >= 1 and p0 >= 1
+        assert features.shape == (n, self.F) and features.dtype == torch.float32 and features.is_contiguous()
+        ws = self._buffers(n, p0, s)
+        P, V, R = self.P, self.V, self.R
+        t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
+        tokT = ws["tokT"]
+        if mode == hip.FORCED:
+            tokT.copy_(forced_tokens.t())
+        else:
+            tokT[:p0].copy_(prefix.t())
+        if mode == hip.SAMPLE:
+            assert uniforms is not None and uniforms.dtype == torch.float64 and uniforms.numel() >= s * n
+        main = torch.cuda.current_stream()
+
+        # ---- 1. policy rollout (models.py:71-84 run incrementally; trainers.py:443-458)
+        Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
+        hip.gemm(features, P["cnn2linear.weight"], Hb[0], bias=P["cnn2linear.bias"])
+        for k in range(t_steps):
+            hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
+            hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"], bias2=P["lstm.bias_hh_l0"])
+            hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True)
+            hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
+            if k >= p0 - 1:
+                st = k - (p0 - 1)
+                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"])
+                hip.sample_tokens(ws["logits"], mode, tokT[k + 1], 1,
+                                  uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
+                                  log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
+                                  entropy=ws["entropy"][st] if mode != hip.GREEDY else None)
+        tok_flat = tokT.view(-1)
+
+        # ---- 2. reward GRU chain on the side stream, value LSTM chain on the main stream
+        side = self._side_stream() if self.concurrent else main
+        ev_tok = torch.cuda.Event()
+        ev_tok.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_tok)
+            hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["XPr"],
+                     a_rows=tok_flat[:l_cols * n], bias=R["rewrnn.gru.bias_ih_l0"])
+            hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
+                              ws["hr"], ws["sync_r"], ws["status"][1:2])
+            hip.gemm(ws["hr"].view(s * n, H), R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
+            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+            hip.cosine_reward(ws["ve"], ws["se"], s * n, n, ws["rewards"])
+            ev_rew = torch.cuda.Event()
+            ev_rew.record(side)
+        hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
+        hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
+                 bias2=V["valrnn.lstm.bias_hh_l0"])
+        hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, ws["hv"],
+                           ws["saved"] if backward else None, ws["sync_v"], ws["status"][0:1])
+        w1 = V["linear1.weight"]
+        hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
+        hip.gemm(ws["hv"].view(s * n, H), w1[:, self.F:], ws["Y"])
+        hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], s * n, n, ws["values"])
+        main.wait_event(ev_rew)
+
+        # ---- 3. loss (trainers.py:471-476)
+        hip.a2c_loss(ws["values"], ws["rewards"], ws["logp"].view(-1), ws["scalars"],
+                     ws["dvalue"] if backward else None, ws["dlogp"] if backward else None)
+        if backward and mode != hip.GREEDY:
+            self._backward(ws, features, n, p0, s, main, side)
+
+        return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
+                             ws["rewards"].view(s, n).t().contiguous(), ws["scalars"], ws["entropy"], ws["status"])
+
+    # ------------------------------------------------------------------ gradients
+    def _backward(self, ws, features, n, p0, s, main, side):
+        P, V = self.P, self.V
+        gP, gV = self.gP, self.gV
+        t_steps, lv, tv = p0 - 1 + s, p0 + s - 1, ws["tv"]
+        tok_flat = ws["tokT"].view(-1)
+        ev_loss = torch.cuda.Event()
+        ev_loss.record(main)
+
+        # ---- value network: head, then the chain's BPTT (main stream)
+        dvalue = ws["dvalue"].view(s * n, 1)
+        dY = ws["dY"]
+        hip.gemm(dvalue, V["linear2.weight"], dY, b_kmajor=True)                       # dY = dvalue (x) w2
+        hip.gemm(dvalue, ws["Y"], gV["linear2.weight"], a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
+        hip.colsum(dvalue, gV["linear2.bias"])
+        w1, gw1 = V["linear1.weight"], gV["linear1.weight"]
+        hip.gemm(dY, ws["hv"].view(s * n, H), gw1[:, self.F:], a_kmajor=True, b_kmajor=True)
+        hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1))
+        hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
+        hip.colsum(dY, gV["linear1.bias"])
+        hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
+        hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
+                           ws["sync_v"], ws["status"][2:3])
+
+        # ---- policy network BPTT on the side stream, beside the value chain
+        with torch.cuda.stream(side):
+            side.wait_event(ev_loss)
+            self._policy_backward(ws, features, n, p0, s)
+            ev_pol = torch.cuda.Event()
+            ev_pol.record(side)
+
+        # ---- value network: weight gradients from the chain's gate gradients
+        hip.chain_hprev(ws["saved"], tv, ws["hprev"])
+        hip.gemm(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], a_kmajor=True, b_kmajor=True)
+        hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])
+        hip.gemm(ws["dGsum"], ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], a_kmajor=True, b_kmajor=True)
+        hip.colsum(ws["dGsum"], gV["valrnn.lstm.bias_ih_l0"])
+        gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
+        g_emb = gV.get("valrnn.caption_embedding.weight")
+        if g_emb is not None:
+            hip.gemm(ws["dGsum"], V["valrnn.lstm.weight_ih_l0"], ws["dXv"], b_kmajor=True)
+            g_emb.zero_()
+            hip.scatter_add_rows(g_emb, tok_flat, 1, lv * n, ws["dXv"])
+        main.wait_event(ev_pol)
+
+    def _policy_backward(self, ws, features, n, p0, s):
+        P, gP = self.P, self.gP
+        t_steps = p0 - 1 + s
+        tok_flat = ws["tokT"].view(-1)
+        G = ws["probs"].view(s * n, self.vocab)
+        hip.policy_dlogits(G, tok_flat[p0 * n:], 1, ws["dlogp"])
+        Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
+        hip.gemm(G, Hs, gP["linear2vocab.weight"], a_kmajor=True, b_kmajor=True)
+        hip.colsum(G, gP["linear2vocab.bias"])
+        dHall = ws["dHall"]
+        if p0 > 1:
+            dHall[:p0 - 1].zero_()
+        hip.gemm(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), b_kmajor=True)
+        dgp = ws["dgp"]
+        dc = [ws["dc0"], ws["dc1"]]
+        for k in range(t_steps - 1, -1, -1):
+            hip.lstm_cell_bwd(ws["gates"][k], ws["Cbuf"][k], ws["Cbuf"][k + 1], dHall[k],
+                              None if k == t_steps - 1 else dc[(k + 1) & 1], dgp[k], dc[k & 1])
+            if k > 0:
+                hip.gemm(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], b_kmajor=True, accumulate=True)
+            else:
+                hip.gemm(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], b_kmajor=True)
+        dg_all = dgp.view(t_steps * n, 4 * H)
+        hip.gemm(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], a_kmajor=True, b_kmajor=True)
+        hip.gemm(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], a_kmajor=True,
+                 b_kmajor=True)
+        hip.colsum(dg_all, gP["lstm.bias_ih_l0"])
+        gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
+        g_emb = gP.get("caption_embedding.weight")
+        if g_emb is not None:
+            hip.gemm(dg_all, P["lstm.weight_ih_l0"], ws["dX"], b_kmajor=True)
+            g_emb.zero_()
+            hip.scatter_add_rows(g_emb, tok_flat, 1, t_steps * n, ws["dX"])
+        hip.gemm(ws["dh0"], features, gP["cnn2linear.weight"], a_kmajor=True, b_kmajor=True)
+        hip.colsum(ws["dh0"], gP["cnn2linear.bias"])

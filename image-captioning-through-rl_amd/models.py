@@ -1,0 +1,261 @@
+"""The reference's models.py class surface, computing on the HIP kernels.
+
+Same class names, constructor arguments, attribute names and ``state_dict`` keys as the
+reference (models.py:33-287), so checkpoints written by either side load in the other and
+``from models import *`` call sites keep working.  Differences, all additive:
+  * ``feature_dim`` keyword on ValueNetwork / RewardNetwork (the reference hard-wires
+    512-d PCA features, models.py:160, 250; its own PolicyNetwork already takes
+    ``input_dim``);
+  * ``forward`` runs hand-written gfx950 kernels through the C ABI and builds no autograd
+    graph - gradients of the A2C step come from the fused backward in ``engine.py``;
+  * ``bidirectional=True`` is accepted for signature compatibility and raises
+    NotImplementedError (off by default in the reference, image_captioner.py:172-173).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hipabi as hip
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+MAX_SEQ_LEN = 17  # the max captions len in the dataset (models.py:18)
+H = 512
+
+
+def repackage_hidden(h):
+    """Detach hidden states from their history (models.py:20-30)."""
+    if isinstance(h, torch.Tensor):
+        return h.detach().to(device)
+    return tuple(repackage_hidden(v) for v in h)
+
+
+def _no_bidirectional(flag):
+    if flag:
+        raise NotImplementedError("bidirectional recurrent layers are not built on the HIP path")
+
+
+def _embedding(vocab_size, wordvec_dim, pretrained):
+    if pretrained is not None:
+        emb = nn.Embedding.from_pretrained(torch.FloatTensor(np.asarray(pretrained)), freeze=True)
+        return emb, pretrained.shape[1]
+    return nn.Embedding(vocab_size, wordvec_dim), wordvec_dim
+
+
+def _dev_f32(x, dev):
+    return torch.as_tensor(x, device=dev).float().contiguous()
+
+
+class _ChainWorkspace:
+    """Granule buffer + status word of the persistent chain kernels, per device."""
+
+    def __init__(self):
+        self.sync = None
+        self.status = None
+
+    def get(self, dev):
+        if self.sync is None or self.sync.device != dev:
+            self.sync = torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self.sync, self.status
+
+
+class PolicyNetwork(nn.Module):
+    """Actor: LSTM over caption embeddings, hidden state initialised from the image
+    features, every position projected to the vocabulary (models.py:33-84)."""
+
+    def __init__(self, word_to_idx, input_dim=512, wordvec_dim=512, hidden_dim=512,
+                 pretrained_embeddings=None, bidirectional=False):
+        super().__init__()
+        _no_bidirectional(bidirectional)
+        assert hidden_dim == H, "the HIP kernels are built for hidden_dim = 512"
+        self.bidirectional = bidirectional
+        self.word_to_idx = word_to_idx
+        self.idx_to_word = {i: w for w, i in word_to_idx.items()}
+        vocab_size = len(word_to_idx)
+        self.caption_embedding, wordvec_dim = _embedding(vocab_size, wordvec_dim, pretrained_embeddings)
+        self.cnn2linear = nn.Linear(input_dim, hidden_dim)
+        self.lstm = nn.LSTM(wordvec_dim, hidden_dim, batch_first=True, bidirectional=False)
+        self.linear2vocab = nn.Linear(hidden_dim, vocab_size)
+
+    @torch.no_grad()
+    def forward(self, features, captions):
+        """features [1,N,F], captions [N,p] -> logits [N,p,V] (models.py:71-84)."""
+        w = self.cnn2linear.weight
+        feats = _dev_f32(features, w.device).reshape(-1, w.shape[1])
+        caps = torch.as_tensor(captions, device=w.device).long()
+        n, p = caps.shape
+        tok_t = caps.t().contiguous()
+        hs = torch.empty(p + 1, n, H, device=w.device)
+        c_prev, c_next = torch.zeros(n, H, device=w.device), torch.empty(n, H, device=w.device)
+        gates = torch.empty(n, 4 * H, device=w.device)
+        hip.gemm(feats, w, hs[0], bias=self.cnn2linear.bias)
+        for t in range(p):
+            hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, gates, a_rows=tok_t[t],
+                     bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
+            hip.gemm(hs[t], self.lstm.weight_hh_l0, gates, accumulate=True)
+            hip.lstm_cell_fwd(gates, c_prev, c_next, hs[t + 1])
+            c_prev, c_next = c_next, c_prev
+        vocab = self.linear2vocab.weight.shape[0]
+        logits = torch.empty(p * n, vocab, device=w.device)
+        hip.gemm(hs[1:].view(p * n, H), self.linear2vocab.weight, logits, bias=self.linear2vocab.bias)
+        return logits.view(p, n, vocab).permute(1, 0, 2)
+
+
+class ValueNetworkRNN(nn.Module):
+    """Embedding + LSTM fed (N,1,E) without batch_first: the rows of a minibatch are
+    consecutive time steps of one batch-1 recurrence whose state persists in
+    ``hidden_cell`` until ``init_hidden()`` (models.py:87-135)."""
+
+    def __init__(self, word_to_idx, input_dim=512, wordvec_dim=512, hidden_dim=512,
+                 pretrained_embeddings=None, bidirectional=False):
+        super().__init__()
+        _no_bidirectional(bidirectional)
+        assert hidden_dim == H
+        self.bidirectional = bidirectional
+        self.hidden_dim = hidden_dim
+        self.word_to_idx = word_to_idx
+        self.idx_to_word = {i: w for w, i in word_to_idx.items()}
+        self.caption_embedding, wordvec_dim = _embedding(len(word_to_idx), wordvec_dim, pretrained_embeddings)
+        self.init_hidden()
+        self.lstm = nn.LSTM(wordvec_dim, hidden_dim, bidirectional=False)
+        self._chain_ws = _ChainWorkspace()
+
+    def init_hidden(self):
+        self.hidden_cell = (torch.zeros(1, 1, self.hidden_dim).to(device), torch.zeros(1, 1, self.hidden_dim).to(device))
+
+    @torch.no_grad()
+    def forward_columns(self, tok_t):
+        """tok_t [p, N] int64 (column-major captions): runs the p*N-step chain from
+        ``hidden_cell`` and returns the hidden outputs of the LAST column, [N, H]."""
+        dev = self.lstm.weight_hh_l0.device
+        p, n = tok_t.shape
+        xproj = torch.empty(p * n, 4 * H, device=dev)
+        hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, xproj, a_rows=tok_t.reshape(-1),
+                 bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
+        state = torch.cat((self.hidden_cell[0].reshape(-1), self.hidden_cell[1].reshape(-1))).to(dev).contiguous()
+        state_out = torch.empty_like(state)
+        h_emit = torch.empty(1, n, H, device=dev)
+        sync, status = self._chain_ws.get(dev)
+        hip.lstm_chain_fwd(xproj, self.lstm.weight_hh_l0, n, p, 1, h_emit, None, sync, status, state_in=state,
+                           state_out=state_out)
+        if status.item() != 0:
+            raise RuntimeError("value LSTM chain kernel timed out")
+        self.hidden_cell = (state_out[:H].view(1, 1, H), state_out[H:].view(1, 1, H))
+        return h_emit[0]
+
+    def forward(self, captions):
+        """captions [N] -> [N,1,H] (models.py:130-135)."""
+        caps = torch.as_tensor(captions, device=self.lstm.weight_hh_l0.device).long()
+        return self.forward_columns(caps.view(1, -1)).unsqueeze(1)
+
+
+class ValueNetwork(nn.Module):
+    """Critic: last column's chain outputs concatenated with the image features, two
+    linear layers with no activation between them (models.py:138-180)."""
+
+    def __init__(self, word_to_idx, pretrained_embeddings=None, bidirectional=False, feature_dim=512):
+        super().__init__()
+        _no_bidirectional(bidirectional)
+        self.bidirectional = bidirectional
+        self.valrnn = ValueNetworkRNN(word_to_idx, pretrained_embeddings=pretrained_embeddings, bidirectional=False)
+        self.linear1 = nn.Linear(feature_dim + 512, 512)
+        self.linear2 = nn.Linear(512, 1)
+
+    @torch.no_grad()
+    def forward(self, features, captions):
+        """features [N,F], captions [N,p] -> [N,1] (models.py:166-180)."""
+        dev = self.linear1.weight.device
+        feats = _dev_f32(features, dev)
+        caps = torch.as_tensor(captions, device=dev).long()
+        n = caps.shape[0]
+        f = feats.shape[1]
+        hs = self.valrnn.forward_columns(caps.t().contiguous())
+        u, y = torch.empty(n, 512, device=dev), torch.empty(n, 512, device=dev)
+        hip.gemm(feats, self.linear1.weight[:, :f], u, bias=self.linear1.bias)
+        hip.gemm(hs, self.linear1.weight[:, f:], y)
+        values = torch.empty(n, device=dev)
+        hip.value_head_fwd(y, u, self.linear2.weight, self.linear2.bias, n, n, values)
+        return values.view(n, 1)
+
+
+class RewardNetworkRNN(nn.Module):
+    """Embedding + GRU, batch-as-sequence like ValueNetworkRNN (models.py:183-228)."""
+
+    def __init__(self, word_to_idx, input_dim=512, wordvec_dim=512, hidden_dim=512,
+                 pretrained_embeddings=None, bidirectional=False):
+        super().__init__()
+        _no_bidirectional(bidirectional)
+        assert hidden_dim == H
+        self.bidirectional = bidirectional
+        self.hidden_dim = hidden_dim
+        self.word_to_idx = word_to_idx
+        self.idx_to_word = {i: w for w, i in word_to_idx.items()}
+        self.caption_embedding, wordvec_dim = _embedding(len(word_to_idx), wordvec_dim, pretrained_embeddings)
+        self.init_hidden()
+        self.gru = nn.GRU(wordvec_dim, hidden_dim, bidirectional=False)
+        self._chain_ws = _ChainWorkspace()
+
+    def init_hidden(self):
+        self.hidden_cell = torch.zeros(1, 1, self.hidden_dim).to(device)
+
+    @torch.no_grad()
+    def forward_columns(self, tok_t):
+        dev = self.gru.weight_hh_l0.device
+        p, n = tok_t.shape
+        xproj = torch.empty(p * n, 3 * H, device=dev)
+        hip.gemm(self.caption_embedding.weight, self.gru.weight_ih_l0, xproj, a_rows=tok_t.reshape(-1),
+                 bias=self.gru.bias_ih_l0)
+        state = self.hidden_cell.reshape(-1).to(dev).contiguous()
+        state_out = torch.empty_like(state)
+        h_emit = torch.empty(1, n, H, device=dev)
+        sync, status = self._chain_ws.get(dev)
+        hip.gru_chain_fwd(xproj, self.gru.weight_hh_l0, self.gru.bias_hh_l0, n, p, 1, h_emit, sync, status,
+                          state_in=state, state_out=state_out)
+        if status.item() != 0:
+            raise RuntimeError("reward GRU chain kernel timed out")
+        self.hidden_cell = state_out.view(1, 1, H)
+        return h_emit[0]
+
+    def forward(self, captions):
+        caps = torch.as_tensor(captions, device=self.gru.weight_hh_l0.device).long()
+        return self.forward_columns(caps.view(1, -1)).unsqueeze(1)
+
+
+class RewardNetwork(nn.Module):
+    """Projects caption (GRU chain) and image features into one embedding space
+    (models.py:231-262)."""
+
+    def __init__(self, word_to_idx, pretrained_embeddings=None, bidirectional=False, feature_dim=512):
+        super().__init__()
+        _no_bidirectional(bidirectional)
+        self.bidirectional = bidirectional
+        self.rewrnn = RewardNetworkRNN(word_to_idx, pretrained_embeddings=pretrained_embeddings, bidirectional=False)
+        self.visual_embed = nn.Linear(feature_dim, 512)
+        self.semantic_embed = nn.Linear(512, 512)
+
+    @torch.no_grad()
+    def forward(self, features, captions):
+        """-> (visual embeds [N,512], semantic embeds [N,512]) (models.py:253-262)."""
+        dev = self.visual_embed.weight.device
+        feats = _dev_f32(features, dev)
+        caps = torch.as_tensor(captions, device=dev).long()
+        n = caps.shape[0]
+        hs = self.rewrnn.forward_columns(caps.t().contiguous())
+        se, ve = torch.empty(n, 512, device=dev), torch.empty(n, 512, device=dev)
+        hip.gemm(hs, self.semantic_embed.weight, se, bias=self.semantic_embed.bias)
+        hip.gemm(feats, self.visual_embed.weight, ve, bias=self.visual_embed.bias)
+        return ve, se
+
+
+class AdvantageActorCriticNetwork(nn.Module):
+    """Wraps the value and policy networks (models.py:265-287)."""
+
+    def __init__(self, value_network, policy_network):
+        super().__init__()
+        self.value_network = value_network
+        self.policy_network = policy_network
+
+    def forward(self, features, captions):
+        values = self.value_network(features, captions)
+        probs = self.policy_network(torch.as_tensor(features).unsqueeze(0), captions)[:, -1:, :]
+        return values, probs

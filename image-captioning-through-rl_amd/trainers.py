@@ -1,0 +1,242 @@
+"""The reference's A2C entry points (trainers.py) on the HIP path.
+
+Kept: ``GenerateCaptionsGreedy``, ``GetRewards``, ``a2c_training``,
+``a2c_curriculum_training``, ``train_a2c_network`` - same names, argument order and
+meaning, same logged scalar tags, same NumPy / torch RNG consumption (so the same seeds
+give the same minibatch order and the same sampled tokens as the reference).
+Not built here (off the A2C step): the three supervised pre-training loops, the beam
+look-ahead decoder and the evaluation loop (trainers.py:73-105, 125-309, 619-665).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import dist as ddp
+from . import hipabi as hip
+from .engine import A2CEngine
+from .models import (MAX_SEQ_LEN, AdvantageActorCriticNetwork, PolicyNetwork, RewardNetwork, ValueNetwork,
+                     device)
+from .optim import FusedAdam, flatten_module
+from .utilities import get_coco_minibatches, global_minibatch_number, print_green, save_a2c_model
+
+H = 512
+
+
+class ScalarLog:
+    """Stand-in with SummaryWriter's add_scalar when tensorboard is not installed;
+    keeps (tag, value, step) triples in ``records``."""
+
+    def __init__(self, log_dir=None):
+        self.log_dir = log_dir
+        self.records = []
+
+    def add_scalar(self, tag, value, step):
+        self.records.append((tag, float(value), int(step)))
+
+
+def make_writer(plot_dir):
+    if hasattr(plot_dir, "add_scalar"):  # a writer object may be passed instead of a directory
+        return plot_dir
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=os.path.join(plot_dir, 'runs'))
+    except Exception:
+        return ScalarLog(os.path.join(str(plot_dir), 'runs'))
+
+
+def GenerateCaptionsGreedy(features, captions, policy_network):
+    """MAX_SEQ_LEN-1 argmax steps from captions[:, 0:1] -> [N, 17] int64
+    (trainers.py:57-70), with the LSTM state carried instead of recomputing the prefix."""
+    w = policy_network.cnn2linear.weight
+    dev = w.device
+    feats = torch.as_tensor(features, device=dev).float().contiguous()
+    caps = torch.as_tensor(np.asarray(captions)[:, 0:1] if not torch.is_tensor(captions) else captions[:, 0:1],
+                           device=dev).long()
+    n = feats.shape[0]
+    vocab = policy_network.linear2vocab.weight.shape[0]
+    tok_t = torch.zeros(MAX_SEQ_LEN, n, dtype=torch.int64, device=dev)
+    tok_t[0] = caps[:, 0]
+    h = torch.empty(n, H, device=dev)
+    c_prev, c_next = torch.zeros(n, H, device=dev), torch.empty(n, H, device=dev)
+    gates, logits = torch.empty(n, 4 * H, device=dev), torch.empty(n, vocab, device=dev)
+    lstm = policy_network.lstm
+    with torch.no_grad():
+        hip.gemm(feats, w, h, bias=policy_network.cnn2linear.bias)
+        for t in range(MAX_SEQ_LEN - 1):
+            hip.gemm(policy_network.caption_embedding.weight, lstm.weight_ih_l0, gates, a_rows=tok_t[t],
+                     bias=lstm.bias_ih_l0, bias2=lstm.bias_hh_l0)
+            hip.gemm(h, lstm.weight_hh_l0, gates, accumulate=True)
+            hip.lstm_cell_fwd(gates, c_prev, c_next, h)
+            c_prev, c_next = c_next, c_prev
+            hip.gemm(h, policy_network.linear2vocab.weight, logits, bias=policy_network.linear2vocab.bias)
+            hip.sample_tokens(logits, hip.GREEDY, tok_t[t + 1], 1)
+    return tok_t.t().contiguous()
+
+
+def GetRewards(features, captions, reward_network):
+    """Cosine similarity of the reward network's two embeddings -> [N,1]
+    (trainers.py:108-121)."""
+    vis, sem = reward_network(features, captions)
+    n = vis.shape[0]
+    rewards = torch.empty(n, device=vis.device)
+    hip.cosine_reward(vis, sem, n, n, rewards)
+    return rewards.unsqueeze(1)
+
+
+def _params_of(module):
+    return {k: p.data for k, p in module.named_parameters()}
+
+
+def _grads_of(module):
+    grads = {}
+    for k, p in module.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p.data)
+        grads[k] = p.grad
+    return grads
+
+
+def build_engine(a2c_network, reward_network, concurrent=True):
+    """Bind an A2CEngine to the live parameter / gradient storage of the modules."""
+    return A2CEngine(_params_of(a2c_network.policy_network), _params_of(a2c_network.value_network),
+                     _params_of(reward_network), _grads_of(a2c_network.policy_network),
+                     _grads_of(a2c_network.value_network), concurrent=concurrent)
+
+
+def caption_length(captions):
+    """Right-most column holding an <END> (id 2), plus one (trainers.py:436)."""
+    return int(np.nonzero(np.asarray(captions) == 2)[1].max()) + 1
+
+
+def _a2c_minibatch(engine, optimizer, captions, features, p0, n_steps):
+    """Rollout + loss + gradients + update for one minibatch; returns the step result."""
+    dev = engine.device
+    caps_np = np.asarray(captions)
+    n = caps_np.shape[0]
+    feats = torch.as_tensor(features).float().to(dev).contiguous()
+    prefix = torch.as_tensor(caps_np[:, :p0]).long().to(dev)
+    # one double per (step, row), drawn from NumPy's global stream exactly as the reference's
+    # N calls of np.random.choice per step do (trainers.py:447-449)
+    uniforms = torch.from_numpy(np.random.random_sample(n_steps * n)).to(dev)
+    res = engine.step(feats, prefix, n_steps, uniforms=uniforms)
+    flat = getattr(optimizer, "fp", None)
+    if flat is not None:
+        ddp.average_gradients(flat.flat_grad)
+    optimizer.step()
+    return res
+
+
+def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size, epochs):
+    """Advantage-weighted policy-gradient training (trainers.py:402-500)."""
+    writer = make_writer(plot_dir)
+    print_green('[Training] Training Advantage Actor-Critic Network')
+    engine = build_engine(a2c_network, reward_network)
+    best_loss = float('inf')
+    for epoch in range(epochs):
+        for minibatch_id, (captions, features, _) in enumerate(
+                get_coco_minibatches(train_data, batch_size=batch_size, split='train')):
+            caplen = caption_length(captions)
+            res = _a2c_minibatch(engine, optimizer, captions, features, 1, caplen - 1).check()
+            loss, _, _, mean_reward, mean_adv = res.scalars[:5].tolist()
+            best_loss = min(best_loss, loss)
+            step = global_minibatch_number(epoch, minibatch_id, batch_size)
+            writer.add_scalar('A2C Network-episodic-loss', loss, step)
+            writer.add_scalar('A2C Network-episodic-mean-rewards', mean_reward, step)
+            writer.add_scalar('A2C Network-episodic-mean-advantage', mean_adv, step)
+            reward_network.rewrnn.init_hidden()
+            a2c_network.value_network.valrnn.init_hidden()
+        save_a2c_model(a2c_network, save_paths)
+    return a2c_network
+
+
+def a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size,
+                            epochs, curriculum):
+    """Curriculum variant (trainers.py:503-616): for each level, start from the
+    ground-truth prefix captions[:, :caplen-level] and roll out `level` steps; minibatches
+    whose captions are too short for the level are skipped."""
+    writer = make_writer(plot_dir)
+    print_green('[Training] Training Advantage Actor-Critic Network')
+    print_green(f'[Training] mode set to curriculum training using levels: {curriculum}')
+    engine = build_engine(a2c_network, reward_network)
+    for level in curriculum:
+        print_green(f'[Training] Training curriculum level: {level}')
+        for epoch in range(epochs):
+            for minibatch_id, (captions, features, _) in enumerate(
+                    get_coco_minibatches(train_data, batch_size=batch_size, split='train')):
+                curr_seq_len = caption_length(captions) - level
+                if curr_seq_len >= 1:
+                    res = _a2c_minibatch(engine, optimizer, captions, features, curr_seq_len, level).check()
+                    loss, _, _, mean_reward, mean_adv = res.scalars[:5].tolist()
+                    step = global_minibatch_number(epoch, minibatch_id, batch_size)
+                    tag = 'A2C Curriculum' + ' Level-' + str(level)
+                    writer.add_scalar(tag + '-loss', loss, step)
+                    writer.add_scalar(tag + '-mean-rewards', mean_reward, step)
+                    writer.add_scalar(tag + '-mean-advantage', mean_adv, step)
+                reward_network.rewrnn.init_hidden()
+                a2c_network.value_network.valrnn.init_hidden()
+            save_a2c_model(a2c_network, save_paths)
+    return a2c_network
+
+
+def _load_or_fail(net, path, what):
+    try:
+        net.load_state_dict(torch.load(path, map_location=device, weights_only=True), strict=False)
+    except FileNotFoundError as e:
+        raise FileNotFoundError(
+            "%s checkpoint %r not found; the reference would now pre-train it (trainers.py:345-370), "
+            "but the supervised pre-training loops are outside the A2C hot path built here" % (what, path)) from e
+    print(f'[Training] loaded {what}')
+    return net
+
+
+def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirectional, epochs, batch_size,
+                      retrain_all=False, curriculum=None):
+    """Entry point (trainers.py:312-399): load the three pre-trained networks, freeze the
+    reward network, Adam(lr=1e-4) over value + policy, dispatch to the plain or the
+    curriculum loop, append the network description to the results file."""
+    if retrain_all:
+        raise NotImplementedError("retrain_all runs the supervised pre-training loops "
+                                  "(trainers.py:125-309), which are outside the A2C hot path built here")
+    model_save_path = save_paths["model_path"]
+    results_save_path = save_paths["results_path"]
+    w2i, emb = train_data["word_to_idx"], train_data["embeddings"]
+    fdim = int(np.asarray(train_data["train_features"]).shape[1])
+    reward_network = _load_or_fail(RewardNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional,
+                                                 feature_dim=fdim).to(device),
+                                   network_paths["reward_network"], "reward network")
+    policy_network = _load_or_fail(PolicyNetwork(w2i, input_dim=fdim, pretrained_embeddings=emb,
+                                                 bidirectional=bidirectional).to(device),
+                                   network_paths["policy_network"], "policy network")
+    value_network = _load_or_fail(ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional,
+                                               feature_dim=fdim).to(device),
+                                  network_paths["value_network"], "value network")
+    reward_network.requires_grad_(False)
+    reward_network.train(False)
+    a2c_network = AdvantageActorCriticNetwork(value_network, policy_network).to(device)
+    a2c_network.train(True)
+    flat = flatten_module(a2c_network)
+    ddp.broadcast_parameters(flat.flat)
+    optimizer = FusedAdam(flat, lr=0.0001)
+
+    print(f'[Training] train_data len = {len(train_data["train_captions"])}')
+    print(f'[Training] episodes = {batch_size}')
+    print(f'[Training] epochs = {epochs}')
+
+    save_paths = [model_save_path, network_paths["a2c_network"]]
+    if curriculum is None:
+        a2c_network = a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths,
+                                   batch_size, epochs)
+    else:
+        if 16 not in curriculum:
+            curriculum.append(16)  # Final Curriculum Level, ie Full Training
+        a2c_network = a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir,
+                                              save_paths, batch_size, epochs, curriculum)
+    with open(results_save_path, 'a') as f:
+        f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
+        f.write(str(a2c_network))
+        f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
+    return a2c_network

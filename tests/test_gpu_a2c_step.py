@@ -1,0 +1,213 @@
+"""The fused A2C minibatch on the GPU against (a) vectors produced by the reference itself
+and (b) the float64 CPU oracle on larger seeded inputs.  Needs an MI355X: -m gpu.
+
+Tolerances (float32 kernels vs the reference's float32 CPU arithmetic / float64 oracle):
+  log-probs, values, rewards, loss      rtol 2e-4, atol 2e-5
+  gradients                             rtol 2e-3 of the tensor's rms (+1e-7)
+  parameters after Adam                 rtol 1e-5, atol 2e-6
+  greedy / sampled token ids            bit-exact (sampled: except draws within 1e-6 of a CDF edge)
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN_A2C, GOLDEN_CURRICULUM, check_summary, load_golden, params_for, synthetic
+from oracle import a2c_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+hip = importlib.import_module("image-captioning-through-rl_amd.hipabi")
+models = importlib.import_module("image-captioning-through-rl_amd.models")
+trainers = importlib.import_module("image-captioning-through-rl_amd.trainers")
+optim = importlib.import_module("image-captioning-through-rl_amd.optim")
+
+RTOL, ATOL = 2e-4, 2e-5
+
+
+def build_modules(cfg):
+    w2i = synthetic.make_word_to_idx(cfg["vocab"])
+    pol = models.PolicyNetwork(w2i, input_dim=cfg["fdim"])
+    val = models.ValueNetwork(w2i, feature_dim=cfg["fdim"])
+    rew = models.RewardNetwork(w2i, feature_dim=cfg["fdim"])
+    for net, params in zip((pol, val, rew), params_for(cfg)):
+        assert list(net.state_dict().keys()) == list(params.keys())
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        net.cuda()
+    rew.requires_grad_(False)
+    a2c = models.AdvantageActorCriticNetwork(val, pol).cuda()
+    return a2c, rew
+
+
+def run_step(a2c, rew, features, captions, p0, steps, **kw):
+    engine = trainers.build_engine(a2c, rew)
+    feats = torch.as_tensor(features).float().cuda().contiguous()
+    prefix = torch.as_tensor(np.asarray(captions)[:, :p0]).long().cuda()
+    return engine.step(feats, prefix, steps, **kw).check()
+
+
+def shape_of(g):
+    cfg = g["cfg"]
+    steps = cfg["caplen"] - 1 if cfg["level"] is None else cfg["level"]
+    return g["tokens"].shape[1] - steps, steps
+
+
+@pytest.mark.parametrize("name", GOLDEN_A2C + GOLDEN_CURRICULUM)
+def test_sampled_tokens_match_reference(name):
+    g = load_golden(name)
+    a2c, rew = build_modules(g["cfg"])
+    p0, steps = shape_of(g)
+    res = run_step(a2c, rew, g["features"], g["captions"], p0, steps,
+                   uniforms=torch.from_numpy(g["uniforms"]).cuda(), backward=False)
+    toks = res.tokens.cpu().numpy()
+    same = toks[:, p0:] == g["tokens"][:, p0:]
+    fragile = g["cdf_edge"].T < 1e-6
+    assert np.all(same | fragile), "sampled token differs away from a CDF edge"
+    assert np.array_equal(toks[:, :p0], g["captions"][:, :p0])
+
+
+@pytest.mark.parametrize("name", GOLDEN_A2C + GOLDEN_CURRICULUM)
+def test_step_outputs_gradients_and_adam_match_reference(name):
+    g = load_golden(name)
+    a2c, rew = build_modules(g["cfg"])
+    flat = optim.flatten_module(a2c)
+    opt = optim.FusedAdam(flat, lr=1e-4)
+    p0, steps = shape_of(g)
+    res = run_step(a2c, rew, g["features"], g["captions"], p0, steps, mode=hip.FORCED,
+                   forced_tokens=torch.from_numpy(g["tokens"]).cuda())
+    np.testing.assert_allclose(res.log_probs.cpu().numpy(), g["log_probs"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.values.cpu().numpy(), g["values"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.rewards.cpu().numpy(), g["rewards"], rtol=RTOL, atol=ATOL)
+    loss, mean_reward, mean_adv = g["scalars_step1"]
+    sc = res.scalars.cpu().numpy()
+    assert abs(sc[0] - loss) <= RTOL * abs(loss) + 2e-6
+    assert abs(sc[3] - mean_reward) <= RTOL * abs(mean_reward) + 2e-6
+    assert abs(sc[4] - mean_adv) <= RTOL * abs(mean_adv) + 2e-6
+    for k, p in a2c.named_parameters():
+        check_summary(g, "grad", k, p.grad.cpu().numpy(), 2e-3, 1e-7)
+    opt.step()
+    torch.cuda.synchronize()
+    for k, p in a2c.named_parameters():
+        check_summary(g, "param1", k, p.data.cpu().numpy(), 1e-5, 2e-6)
+
+
+@pytest.mark.parametrize("name", GOLDEN_A2C)
+def test_greedy_ids_bit_exact(name):
+    g = load_golden(name)
+    cfg = g["cfg"]
+    a2c, _ = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    toks = trainers.GenerateCaptionsGreedy(feats, caps, a2c.policy_network)
+    assert toks.dtype == torch.int64 and tuple(toks.shape) == (cfg["n"], 17)
+    assert g["greedy_margins"].min() > 1e-5
+    assert np.array_equal(toks.cpu().numpy(), g["greedy_tokens"])
+
+
+def test_a2c_training_entry_point_two_minibatches():
+    """trainers.a2c_training driven exactly as the golden generator drove the reference:
+    same torch / NumPy seeds, one minibatch per epoch, two epochs."""
+    g = load_golden("a2c_n4_v100_l10_f512_s0")
+    cfg = g["cfg"]
+    a2c, rew = build_modules(cfg)
+    flat = optim.flatten_module(a2c)
+    opt = optim.FusedAdam(flat, lr=1e-4)
+    data = synthetic.make_train_data(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    log = trainers.ScalarLog()
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    trainers.a2c_training(data, a2c, rew, opt, log, [], cfg["n"], 2)
+    tags = [r[0] for r in log.records]
+    assert tags[:3] == ['A2C Network-episodic-loss', 'A2C Network-episodic-mean-rewards',
+                        'A2C Network-episodic-mean-advantage']
+    assert [r[2] for r in log.records] == [0, 0, 0, 4, 4, 4]  # epoch * batch_size + batch_id
+    got1 = np.array([r[1] for r in log.records[:3]])
+    got2 = np.array([r[1] for r in log.records[3:6]])
+    np.testing.assert_allclose(got1, g["scalars_step1"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(got2, g["scalars_step2"], rtol=1e-3, atol=1e-5)
+    for k, p in a2c.named_parameters():
+        check_summary(g, "param2", k, p.data.cpu().numpy(), 1e-5, 3e-6)
+
+
+def test_curriculum_entry_point_and_skip():
+    g = load_golden("a2c_curriculum3_n4_v100_l10_f512_s0")
+    cfg = g["cfg"]
+    a2c, rew = build_modules(cfg)
+    opt = optim.FusedAdam(optim.flatten_module(a2c), lr=1e-4)
+    data = synthetic.make_train_data(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    log = trainers.ScalarLog()
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    trainers.a2c_curriculum_training(data, a2c, rew, opt, log, [], cfg["n"], 1, [3, 12])
+    # level 12 > caplen 10: every minibatch skipped, nothing logged for it
+    assert [r[0] for r in log.records] == ['A2C Curriculum Level-3-loss', 'A2C Curriculum Level-3-mean-rewards',
+                                           'A2C Curriculum Level-3-mean-advantage']
+    np.testing.assert_allclose([r[1] for r in log.records], g["scalars_step1"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,vocab,caplen,fdim", [(32, 1000, 8, 2048), (3, 50, 4, 512)])
+def test_step_matches_float64_oracle_full_gradients(n, vocab, caplen, fdim):
+    cfg = dict(n=n, vocab=vocab, caplen=caplen, fdim=fdim, seed=5, level=None)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(n, vocab, caplen, fdim, 5)
+    steps = caplen - 1
+    u = synthetic.make_uniforms(5, steps * n)
+    res = run_step(a2c, rew, feats, caps, 1, steps, uniforms=torch.from_numpy(u).cuda())
+    toks = res.tokens.cpu().numpy()
+    pol, val, rw = params_for(cfg)
+    want = orc.a2c_step(pol, val, rw, feats, caps, forced_tokens=toks)
+    free = orc.a2c_step(pol, val, rw, feats, caps, uniforms=u, want_grads=False)
+    assert (free["tokens"] == toks).mean() > 0.995
+    np.testing.assert_allclose(res.log_probs.cpu().numpy(), want["log_probs"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.values.cpu().numpy(), want["values"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.rewards.cpu().numpy(), want["rewards"], rtol=RTOL, atol=ATOL)
+    sc = res.scalars.cpu().numpy()
+    np.testing.assert_allclose(sc[:5], [want["loss"], want["actor_loss"], want["critic_loss"], want["mean_reward"],
+                                        want["mean_advantage"]], rtol=RTOL, atol=2e-6)
+    ent = res.entropy.cpu().numpy()
+    assert np.all(ent > 0) and np.all(ent <= np.log(vocab) + 1e-4)
+    for prefix, grads in (("policy_network.", want["policy_grads"]), ("value_network.", want["value_grads"])):
+        mod = dict(a2c.named_parameters())
+        for k, gw in grads.items():
+            got = mod[prefix + k].grad.cpu().numpy().astype(np.float64)
+            scale = np.sqrt((gw ** 2).mean()) + 1e-12
+            assert np.abs(got - gw).max() <= 2e-3 * scale + 1e-7, (k, np.abs(got - gw).max(), scale)
+
+
+def test_module_forwards_carry_hidden_state_like_the_reference():
+    """models.py surface: ValueNetwork / RewardNetwork / PolicyNetwork.forward, with the
+    recurrent state surviving across calls until init_hidden()."""
+    cfg = dict(n=6, vocab=80, caplen=6, fdim=512, seed=2, level=None)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(6, 80, 6, 512, 2)
+    pol, val, rw = params_for(cfg)
+    Vp, Rp, Pp = orc.to_t(val), orc.to_t(rw), orc.to_t(pol)
+    toks = torch.from_numpy(caps)
+    # two successive calls on growing prefixes == the oracle's chained recurrence
+    want_v = orc.value_forward(Vp, feats, toks, 2, 2).numpy()
+    want_r = orc.reward_forward(Rp, feats, toks, 2, 2).numpy()
+    a2c.value_network.valrnn.init_hidden()
+    rew.rewrnn.init_hidden()
+    for s in range(2):
+        v = a2c.value_network(torch.from_numpy(feats).cuda(), toks[:, :2 + s].cuda())
+        r = trainers.GetRewards(torch.from_numpy(feats).cuda(), toks[:, :3 + s].cuda(), rew)
+        assert tuple(v.shape) == (6, 1) and tuple(r.shape) == (6, 1)
+        np.testing.assert_allclose(v[:, 0].cpu().numpy(), want_v[:, s], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(r[:, 0].cpu().numpy(), want_r[:, s], rtol=RTOL, atol=ATOL)
+    a2c.value_network.valrnn.init_hidden()
+    v0 = a2c.value_network(torch.from_numpy(feats).cuda(), toks[:, :2].cuda())
+    np.testing.assert_allclose(v0[:, 0].cpu().numpy(), want_v[:, 0], rtol=RTOL, atol=ATOL)
+    out = a2c.value_network.valrnn(toks[:, 0].cuda())
+    assert tuple(out.shape) == (6, 1, 512)
+    # policy: logits for every prefix position, [N, p, V]
+    logits = a2c.policy_network(torch.from_numpy(feats).cuda().unsqueeze(0), toks[:, :4].cuda())
+    _, want_l, _ = orc.policy_rollout(Pp, feats, caps[:, :1], 4, mode="forced", forced=caps[:, 1:5])
+    assert tuple(logits.shape) == (6, 4, 80)
+    np.testing.assert_allclose(logits.permute(1, 0, 2).cpu().numpy(), want_l.numpy(), rtol=RTOL, atol=ATOL)
+    values, probs = a2c(torch.from_numpy(feats).cuda(), toks[:, :3].cuda())
+    assert tuple(values.shape) == (6, 1) and tuple(probs.shape) == (6, 1, 80)
+
+
+def test_bidirectional_is_rejected_loudly():
+    with pytest.raises(NotImplementedError):
+        models.PolicyNetwork({"a": 0, "b": 1}, bidirectional=True)
