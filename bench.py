@@ -1,0 +1,171 @@
+"""Throughput of the A2C caption-training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full a2c_training minibatch (trainers.py:426-496): policy rollout with
+sampling, value + reward chains, loss, backward through policy and value networks,
+gradient all-reduce across ranks (N > 1), Adam.  Workload = BASELINE.json configs[2]:
+batch 512 per GPU, 2048-d features, vocab 10k, caption length T = 20, float32 arithmetic.
+Inputs (features, start tokens, uniforms) are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "image-captioning-through-rl_amd"
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense, MI355X
+
+
+def build_networks(syn, models, optim, vocab, fdim, seed, dev):
+    w2i = syn.make_word_to_idx(vocab)
+    nets = (models.PolicyNetwork(w2i, input_dim=fdim), models.ValueNetwork(w2i, feature_dim=fdim),
+            models.RewardNetwork(w2i, feature_dim=fdim))
+    params = [syn.make_params(k, vocab, fdim, seed) for k in ("policy", "value", "reward")]
+    for net, p in zip(nets, params):
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+        net.to(dev)
+    pol, val, rew = nets
+    rew.requires_grad_(False)
+    a2c = models.AdvantageActorCriticNetwork(val, pol).to(dev)
+    flat = optim.flatten_module(a2c)
+    return a2c, rew, flat, params
+
+
+def cpu_baseline(syn, params, vocab, caplen, fdim, sample_batch):
+    """The reference-shaped float32 CPU port (oracle/cpu_port.py), one minibatch of
+    `sample_batch` rows of the same workload, on this host's cores."""
+    from oracle import cpu_port
+    nets = cpu_port.PortNets(params[0], params[1], params[2], vocab, fdim)
+    opt = cpu_port.make_optimizer(nets)
+    feats, caps = syn.make_minibatch(sample_batch, vocab, caplen, fdim, 0)
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    cpu_port.a2c_minibatch(nets, opt, feats, caps)
+    dt = time.perf_counter() - t0
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 A2C minibatch of %d rows (vocab %d, T=%d, %d-d features), float32 torch-CPU, %.1f s"
+                      % (sample_batch, vocab, caplen, fdim, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="rows per GPU")
+    ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--caplen", type=int, default=20)
+    ap.add_argument("--fdim", type=int, default=2048)
+    ap.add_argument("--cpu-sample-batch", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    syn = importlib.import_module(PKG + ".synthetic")
+    hip = importlib.import_module(PKG + ".hipabi")
+    models = importlib.import_module(PKG + ".models")
+    optim = importlib.import_module(PKG + ".optim")
+    trainers = importlib.import_module(PKG + ".trainers")
+    ddp = importlib.import_module(PKG + ".dist")
+
+    rank, world, local = ddp.init_from_env("nccl")
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n, vocab, caplen, fdim = args.batch, args.vocab, args.caplen, args.fdim
+    steps_per_rollout = caplen - 1
+
+    a2c, rew, flat, params = build_networks(syn, models, optim, vocab, fdim, 0, dev)
+    opt = optim.FusedAdam(flat, lr=1e-4)
+    engine = trainers.build_engine(a2c, rew)
+    feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, rank)  # a different shard per rank
+    feats_d = torch.from_numpy(feats).to(dev)
+    prefix_d = torch.from_numpy(caps[:, :1]).to(dev)
+    total_steps = args.warmup + args.steps
+    uniforms = torch.from_numpy(
+        np.random.RandomState(1000 + rank).random_sample((total_steps, steps_per_rollout * n))).to(dev)
+
+    def one_step(i):
+        res = engine.step(feats_d, prefix_d, steps_per_rollout, uniforms=uniforms[i])
+        ddp.average_gradients(flat.flat_grad)
+        opt.step()
+        return res.check()  # reads the status word back: one host sync per step, as .item() in the reference loop
+
+    for i in range(args.warmup):
+        one_step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    hip.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = ddp.max_over_ranks(time.perf_counter() - t0, dev)
+    prof, hip.PROFILE = hip.PROFILE, None
+
+    # per-kernel accounting from the HIP events recorded on each launch's own stream
+    acc = {}
+    for kind, work, e0, e1 in prof:
+        a = acc.setdefault(kind, [0.0, 0.0, 0])
+        a[0] += work
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    gemm_flops, gemm_s, gemm_launches = acc["gemm"]
+    achieved = gemm_flops / gemm_s / 1e12
+    chains = {k: {"dependent_steps_per_minibatch": int(v[0] / args.steps), "us_per_step": 1e6 * v[1] / v[0],
+                  "ms_per_minibatch": 1e3 * v[1] / args.steps}
+              for k, v in acc.items() if k != "gemm"}
+    # minimal-algorithm FLOPs of the policy path per image (fwd x3 for fwd+bwd)
+    e_dim = h_dim = 512
+    fwd = 2 * fdim * h_dim + steps_per_rollout * (2 * (e_dim + h_dim) * 4 * h_dim + 2 * h_dim * vocab)
+    policy_flops_per_image = 3 * fwd
+    value = world * n * args.steps / elapsed
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec per A2C train step (batch 512, T=20, vocab 10k)",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "A2C minibatch: batch %d per GPU, %d-d features, vocab %d, T=%d "
+                                   "(BASELINE.json configs[2]%s)" % (n, fdim, vocab, caplen,
+                                                                     "; configs[3] data-parallel" if world > 1 else ""),
+                       "global_batch": world * n, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "gemm_f32_kernel, all launches of a step (policy LSTM/vocab GEMMs fwd+bwd, "
+                                   "chain input projections and weight gradients)",
+                         "launches_per_step": gemm_launches // args.steps,
+                         "gflop_per_step": gemm_flops / args.steps / 1e9,
+                         "ms_per_step_in_kernel": 1e3 * gemm_s / args.steps},
+            "chains": chains,
+            "lstm_gemm_roofline_of_whole_step": {
+                "policy_flops_per_image_fwd_bwd": policy_flops_per_image,
+                "achieved_tflops": policy_flops_per_image * value / world / 1e12,
+                "frac_of_f32_mfma_peak": policy_flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS},
+            "last_loss": float(res.scalars[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(syn, params, vocab, caplen, fdim, args.cpu_sample_batch)
+            out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,31 @@ ABI_VERSION = 1
 
 _lib = None
 
+# When set to a list, gemm() and the chain launchers bracket each launch with HIP events
+# recorded on the stream the kernel is launched on and append (kind, work, start, end);
+# `work` is the launch's algorithmic FLOPs (GEMM) or dependent steps (chains).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, work):
+        self.kind, self.work = kind, work
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.append((self.kind, self.work, self.e0, self.e1))
+
+
+def chain_positions(n, p0, n_calls):
+    return n * sum(p0 + s for s in range(n_calls))
+
 
 class HipExtensionMissing(RuntimeError):
     pass
@@ -117,8 +142,9 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     ldc = out.stride(0) if ldc is None else ldc
     if a_rows is not None:
         assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
-    rc = load().icrl_gemm_f32(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor), _ptr(out),
-                              ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), _stream())
+    with _Timed("gemm", 2.0 * m * n * k):
+        rc = load().icrl_gemm_f32(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor),
+                                  _ptr(out), ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), _stream())
     _check(rc, "icrl_gemm_f32")
     return out
 
@@ -176,21 +202,26 @@ def chain_sync_bytes():
 
 def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, state_in=None, state_out=None):
     """p0 = caption columns seen by the first call; call s covers p0 + s columns."""
-    _check(load().icrl_lstm_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, _ptr(_f32c(h_emit)),
-                                      _ptr(saved), _ptr(state_in), _ptr(state_out), _ptr(sync_ws), _ptr(status),
-                                      _stream()), "icrl_lstm_chain_fwd")
+    with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
+        rc = load().icrl_lstm_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, _ptr(_f32c(h_emit)),
+                                        _ptr(saved), _ptr(state_in), _ptr(state_out), _ptr(sync_ws), _ptr(status),
+                                        _stream())
+    _check(rc, "icrl_lstm_chain_fwd")
 
 
 def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, state_in=None, state_out=None):
-    _check(load().icrl_gru_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
-                                     _ptr(_f32c(h_emit)), _ptr(state_in), _ptr(state_out), _ptr(sync_ws),
-                                     _ptr(status), _stream()), "icrl_gru_chain_fwd")
+    with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
+        rc = load().icrl_gru_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
+                                       _ptr(_f32c(h_emit)), _ptr(state_in), _ptr(state_out), _ptr(sync_ws),
+                                       _ptr(status), _stream())
+    _check(rc, "icrl_gru_chain_fwd")
 
 
 def lstm_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates, sync_ws, status):
-    _check(load().icrl_lstm_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
-                                      _ptr(_f32c(dgates)), _ptr(sync_ws), _ptr(status), _stream()),
-           "icrl_lstm_chain_bwd")
+    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
+        rc = load().icrl_lstm_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
+                                        _ptr(_f32c(dgates)), _ptr(sync_ws), _ptr(status), _stream())
+    _check(rc, "icrl_lstm_chain_bwd")
 
 
 def chain_fold_calls(dgates, n, p0, n_calls, width, out):

@@ -1,0 +1,48 @@
+"""The N > 1 path on CPU: two gloo ranks, flat-gradient averaging, parameter broadcast,
+row sharding, max-over-ranks timing.  No GPU needed."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddp = importlib.import_module("image-captioning-through-rl_amd.dist")
+    optim = importlib.import_module("image-captioning-through-rl_amd.optim")
+    r, w, _ = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world) and ddp.world_size() == world
+    # every rank starts from rank 0's parameters
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    flat = optim.flatten_module(net)
+    ddp.broadcast_parameters(flat.flat)
+    # rank-dependent gradients, written through the per-parameter views
+    for i, p in enumerate(net.parameters()):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    ddp.average_gradients(flat.flat_grad)
+    lo, hi = ddp.shard_rows(1024)
+    t = ddp.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    torch.save(dict(flat=flat.flat.clone(), grads=[p.grad.clone() for p in net.parameters()], shard=(lo, hi), t=t,
+                    keys=list(net.state_dict().keys())), os.path.join(out_dir, "r%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_average_and_broadcast(tmp_path):
+    world, port = 2, 29500 + os.getpid() % 1000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=False)
+    assert torch.equal(r0["flat"], r1["flat"]), "parameters differ after broadcast"
+    for i, (g0, g1) in enumerate(zip(r0["grads"], r1["grads"])):
+        want = (1 + 2) / 2.0 * (i + 1)  # mean over ranks of (rank+1)*(i+1)
+        assert torch.allclose(g0, torch.full_like(g0, want)) and torch.equal(g0, g1)
+    assert r0["shard"] == (0, 512) and r1["shard"] == (512, 1024)
+    assert r0["t"] == r1["t"] == 2.0
+    assert r0["keys"] == ["0.weight", "0.bias", "1.weight", "1.bias"]

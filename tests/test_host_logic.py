@@ -1,0 +1,93 @@
+"""Host-side logic of the drop-in surface that needs no GPU."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synthetic
+
+models = importlib.import_module("image-captioning-through-rl_amd.models")
+trainers = importlib.import_module("image-captioning-through-rl_amd.trainers")
+utilities = importlib.import_module("image-captioning-through-rl_amd.utilities")
+optim = importlib.import_module("image-captioning-through-rl_amd.optim")
+hip = importlib.import_module("image-captioning-through-rl_amd.hipabi")
+
+
+def test_state_dict_keys_and_shapes_match_the_reference_layout():
+    vocab, fdim = 37, 2048
+    w2i = synthetic.make_word_to_idx(vocab)
+    nets = dict(policy=models.PolicyNetwork(w2i, input_dim=fdim), value=models.ValueNetwork(w2i, feature_dim=fdim),
+                reward=models.RewardNetwork(w2i, feature_dim=fdim))
+    for kind, net in nets.items():
+        want = synthetic.make_params(kind, vocab, fdim, 0)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(want.keys())
+        assert all(tuple(sd[k].shape) == want[k].shape for k in sd)
+    a2c = models.AdvantageActorCriticNetwork(nets["value"], nets["policy"])
+    keys = list(a2c.state_dict().keys())
+    assert keys[0] == "value_network.valrnn.caption_embedding.weight"
+    assert "policy_network.linear2vocab.bias" in keys and len(keys) == 18
+    assert models.MAX_SEQ_LEN == 17
+    assert nets["value"].valrnn.hidden_cell[0].shape == (1, 1, 512)
+    assert nets["reward"].rewrnn.hidden_cell.shape == (1, 1, 512)
+
+
+def test_pretrained_embeddings_are_frozen_and_set_the_word_vector_width():
+    emb = np.random.RandomState(0).standard_normal((20, 300)).astype(np.float32)
+    pol = models.PolicyNetwork(synthetic.make_word_to_idx(20), pretrained_embeddings=emb)
+    assert not pol.caption_embedding.weight.requires_grad
+    assert pol.lstm.weight_ih_l0.shape == (2048, 300)
+    with pytest.raises(NotImplementedError):
+        models.ValueNetwork(synthetic.make_word_to_idx(20), bidirectional=True)
+
+
+def test_minibatch_iterator_order_and_caption_length():
+    data = synthetic.make_train_data(10, 50, 7, 16, 3, max_len=9)
+    torch.manual_seed(11)
+    perm = torch.randperm(10).numpy()
+    torch.manual_seed(11)
+    batches = list(utilities.get_coco_minibatches(data, batch_size=4))
+    assert [b[0].shape[0] for b in batches] == [4, 4, 2]
+    got = np.concatenate([b[0] for b in batches])
+    assert np.array_equal(got, data["train_captions"][perm])
+    assert np.array_equal(np.concatenate([b[1] for b in batches]), data["train_features"][perm])
+    assert trainers.caption_length(data["train_captions"]) == 7
+    assert utilities.global_minibatch_number(3, 5, 512) == 3 * 512 + 5
+    assert utilities.get_filename("a2c.pt", False, [3]) == "a2c_curriculum.pt"
+    assert utilities.get_filename("a2c.pt", True) == "a2c_bidirectional.pt"
+
+
+def test_flatten_module_keeps_values_and_aliases_one_buffer():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = optim.flatten_module(net)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k])
+    assert flat.flat.numel() % 64 == 0
+    flat.flat.zero_()
+    assert all(float(p.detach().abs().sum()) == 0 for p in net.parameters())
+    flat.flat_grad.fill_(2.0)
+    assert all(float(p.grad.min()) == 2.0 for p in net.parameters())
+
+
+def test_scalar_log_and_missing_library_message(monkeypatch, tmp_path):
+    log = trainers.make_writer(trainers.ScalarLog())
+    log.add_scalar("x", torch.tensor(1.5), 3)
+    assert log.records == [("x", 1.5, 3)]
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(hip.HipExtensionMissing, match="no CPU fallback"):
+        hip.load()
+
+
+def test_train_a2c_network_refuses_what_is_out_of_scope(tmp_path):
+    data = synthetic.make_train_data(4, 30, 5, 512, 0)
+    paths = dict(reward_network=str(tmp_path / "r.pt"), policy_network=str(tmp_path / "p.pt"),
+                 value_network=str(tmp_path / "v.pt"), a2c_network=str(tmp_path / "a.pt"))
+    save = dict(model_path=str(tmp_path / "m.pt"), results_path=str(tmp_path / "res.txt"))
+    with pytest.raises(FileNotFoundError, match="pre-train"):
+        trainers.train_a2c_network(data, save, paths, str(tmp_path), False, 1, 4)
+    with pytest.raises(NotImplementedError):
+        trainers.train_a2c_network(data, save, paths, str(tmp_path), False, 1, 4, retrain_all=True)

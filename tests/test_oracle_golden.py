@@ -99,3 +99,24 @@ def test_curriculum_skips_short_captions():
     pol, val, rew = params_for(cfg)
     feats, caps = synthetic.make_minibatch(4, 100, 5, 512, 0)
     assert orc.a2c_step(pol, val, rew, feats, caps, uniforms=np.zeros(64), level=6) is None
+
+
+@pytest.mark.parametrize("name", ["a2c_n4_v100_l10_f512_s0", "a2c_n4_v100_l10_f4096_s0"])
+def test_cpu_port_matches_reference(name):
+    """The reference-shaped float32 port that bench.py times as the CPU baseline."""
+    from oracle import cpu_port
+    g = load_golden(name)
+    cfg = g["cfg"]
+    pol, val, rew = params_for(cfg)
+    nets = cpu_port.PortNets(pol, val, rew, cfg["vocab"], cfg["fdim"])
+    opt = cpu_port.make_optimizer(nets)
+    np.random.seed(cfg["seed"])
+    out = cpu_port.a2c_minibatch(nets, opt, g["features"], g["captions"])
+    same = out["tokens"] == g["tokens"]
+    assert np.all(same[:, 1:] | (g["cdf_edge"].T < 1e-6))
+    loss, mean_reward, mean_adv = g["scalars_step1"]
+    assert abs(out["loss"] - loss) <= 1e-4 * abs(loss) + 1e-6
+    assert abs(out["mean_reward"] - mean_reward) <= 1e-4 * abs(mean_reward) + 1e-6
+    for k, p in nets.named_trainable():
+        check_summary(g, "grad", k, p.grad.numpy(), 1e-3, 1e-7)
+        check_summary(g, "param1", k, p.detach().numpy(), 1e-5, 1e-6)
