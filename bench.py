@@ -157,7 +157,8 @@ def main():
                 "policy_flops_per_image_fwd_bwd": policy_flops_per_image,
                 "achieved_tflops": policy_flops_per_image * value / world / 1e12,
                 "frac_of_f32_mfma_peak": policy_flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS},
-            "last_loss": float(res.scalars[0]),
+            "chain_plan": list(res.chain_plan), "seam_check": engine.last_seam,
+            "seam_fallbacks_in_run": engine.fallbacks, "last_loss": float(res.scalars[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(syn, params, vocab, caplen, fdim, args.cpu_sample_batch)

@@ -31,6 +31,8 @@ struct GemmArgs {
     const float* bias; const float* bias2;
     int accumulate;
     int a_vec, b_vec;  // 1 = 16-byte loads are aligned for this operand
+    int kchunk;        // k-range per blockIdx.y (split-K); a multiple of BK
+    int64_t slab;      // C offset (floats) between split-K partial results
 };
 
 // Load 4 consecutive floats p[0..3] of which the first `valid` exist.
@@ -137,9 +139,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
-    const int nk = (g.K + BK - 1) / BK;
-    tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, 0, g.K, g.a_vec, tid);
-    tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, 0, g.K, g.b_vec, tid);
+    // split-K: blockIdx.y owns k in [kbeg, kend) and writes its own partial slab
+    const int kbeg = blockIdx.y * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    float* const Cout = g.C + (int64_t)blockIdx.y * g.slab;
+    tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg, kend, g.a_vec, tid);
+    tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg, kend, g.b_vec, tid);
     tile_store<BM, A_KM>(lds, ra, tid);
     tile_store<BN, B_KM>(lds + A_TILE, rb, tid);
     __syncthreads();
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
         const float* lb = la + A_TILE;
         if (kt + 1 < nk) {
-            tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, (kt + 1) * BK, g.K, g.a_vec, tid);
-            tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, (kt + 1) * BK, g.K, g.b_vec, tid);
+            tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, tid);
+            tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, tid);
         }
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
@@ -184,13 +190,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int col = n0 + wc * (BN / 2) + j * 32 + l31;
             if (col >= g.N) continue;
             float badd = 0.f;
-            if (g.bias) badd += g.bias[col];
-            if (g.bias2) badd += g.bias2[col];
+            if (g.bias && blockIdx.y == 0) badd += g.bias[col];
+            if (g.bias2 && blockIdx.y == 0) badd += g.bias2[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < g.M) {
-                    float* dst = g.C + (int64_t)row * g.ldc + col;
+                    float* dst = Cout + (int64_t)row * g.ldc + col;
                     float v = acc[i][j][r] + badd;
                     if (g.accumulate) v += *dst;
                     *dst = v;
@@ -200,9 +206,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 }
 
 template <int BM, int BN>
-int launch(const GemmArgs& g, int a_km, int b_km, hipStream_t st) {
+int launch(const GemmArgs& g, int a_km, int b_km, int splits, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles), block(256);
+    dim3 grid(tiles, splits), block(256);
     if (!a_km && !b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
     else if (!a_km && b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
     else if (a_km && !b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
@@ -213,21 +219,51 @@ int launch(const GemmArgs& g, int a_km, int b_km, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
-                             const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
-                             int M, int N, int K, const float* bias, const float* bias2,
-                             int accumulate, icrl_stream_t stream) {
-    ICRL_REQUIRE(A && B && C, "icrl_gemm_f32: null operand");
-    ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "icrl_gemm_f32: empty shape %dx%dx%d", M, N, K);
-    ICRL_REQUIRE(!(a_rows && a_kmajor), "icrl_gemm_f32: row gather needs a_kmajor = 0");
+namespace {
+int gemm_dispatch(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows, const float* B, int64_t ldb,
+                  int b_kmajor, float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2,
+                  int accumulate, int splits, int64_t slab, hipStream_t st, const char* who) {
+    ICRL_REQUIRE(A && B && C, "%s: null operand", who);
+    ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty shape %dx%dx%d", who, M, N, K);
+    ICRL_REQUIRE(!(a_rows && a_kmajor), "%s: row gather needs a_kmajor = 0", who);
     ICRL_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N,
-                 "icrl_gemm_f32: leading dimension smaller than the row length");
+                 "%s: leading dimension smaller than the row length", who);
+    ICRL_REQUIRE(splits >= 1 && splits <= 64, "%s: splits must be in [1, 64]", who);
     GemmArgs g;
     g.A = A; g.lda = lda; g.a_rows = a_rows; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.bias2 = bias2; g.accumulate = accumulate;
     g.a_vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % 4 == 0);
     g.b_vec = (reinterpret_cast<uintptr_t>(B) % 16 == 0) && (ldb % 4 == 0);
-    const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
-    if (big_tiles >= 256) return launch<128, 128>(g, a_kmajor, b_kmajor, icrl::as_stream(stream));
-    return launch<64, 64>(g, a_kmajor, b_kmajor, icrl::as_stream(stream));
+    const int ksteps = (K + BK - 1) / BK;
+    g.kchunk = ((ksteps + splits - 1) / splits) * BK;
+    g.slab = slab;
+    const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits;
+    if (big_tiles >= 256) return launch<128, 128>(g, a_kmajor, b_kmajor, splits, st);
+    return launch<64, 64>(g, a_kmajor, b_kmajor, splits, st);
+}
+}  // namespace
+
+namespace icrl {
+// Used by the host-side chain schedules in this library.
+int gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+         int64_t ldc, int M, int N, int K, int splits, int64_t slab, hipStream_t st) {
+    return gemm_dispatch(A, lda, a_kmajor, nullptr, B, ldb, b_kmajor, C, ldc, M, N, K, nullptr, nullptr, 0,
+                         splits, slab, st, "icrl::gemm");
+}
+}  // namespace icrl
+
+extern "C" int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
+                             const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
+                             int M, int N, int K, const float* bias, const float* bias2,
+                             int accumulate, icrl_stream_t stream) {
+    return gemm_dispatch(A, lda, a_kmajor, a_rows, B, ldb, b_kmajor, C, ldc, M, N, K, bias, bias2, accumulate, 1,
+                         0, icrl::as_stream(stream), "icrl_gemm_f32");
+}
+
+extern "C" int icrl_gemm_f32_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
+                                    int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M, int N,
+                                    int K, int splits, icrl_stream_t stream) {
+    ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f32_splitk: slabs overlap");
+    return gemm_dispatch(A, lda, a_kmajor, nullptr, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, nullptr, 0,
+                         splits, slab_stride, icrl::as_stream(stream), "icrl_gemm_f32_splitk");
 }

@@ -34,6 +34,10 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line) 
 
 static inline hipStream_t as_stream(icrl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// gemm_f32.hip: C (or `splits` partial slabs, `slab` floats apart) = A * B on the f32 MFMA.
+int gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+         int64_t ldc, int M, int N, int K, int splits, int64_t slab, hipStream_t st);
+
 constexpr int kHidden = 512;  // hidden width of every recurrent layer on this path
 
 #if defined(__HIPCC__)

@@ -197,8 +197,8 @@ __global__ __launch_bounds__(1024) void a2c_loss_kernel(const float* __restrict_
     }
 }
 
-// g[r,k] = coef[r] * (onehot(token[r])[k] - p[r,k]), in place over p
-__global__ __launch_bounds__(256) void policy_dlogits_kernel(float* __restrict__ p, int rows, int V,
+// g[r,k] = coef[r] * (onehot(token[r])[k] - p[r,k]); g may alias p
+__global__ __launch_bounds__(256) void policy_dlogits_kernel(const float* p, float* g, int rows, int V,
                                                              const int64_t* __restrict__ tokens,
                                                              int64_t token_stride,
                                                              const float* __restrict__ coef) {
@@ -207,23 +207,37 @@ __global__ __launch_bounds__(256) void policy_dlogits_kernel(float* __restrict__
         const int r = (int)(e / V), k = (int)(e % V);
         const float c = coef[r];
         const float hot = (tokens[r * token_stride] == (int64_t)k) ? 1.f : 0.f;
-        p[e] = c * (hot - p[e]);
+        g[e] = c * (hot - p[e]);
     }
 }
 
 // ---------------------------------------------------------------- Adam
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float lr, float b1, float b2, float eps, float bc1,
-                                                   float bc2_sqrt) {
+                                                   float lr, float b1, float b2, float omb1, float omb2,
+                                                   float eps, float bc1, float bc2_sqrt) {
     // torch.optim.Adam: denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
     const float step_size = lr / bc1;
     for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const float gv = g[e];
-        const float mv = b1 * m[e] + (1.f - b1) * gv;
-        const float vv = b2 * v[e] + (1.f - b2) * gv * gv;
+        // omb = 1 - beta rounded from double, as torch passes it (1.f - 0.999f is off by 1.3e-5 relative)
+        const float mv = b1 * m[e] + omb1 * gv;
+        const float vv = b2 * v[e] + omb2 * gv * gv;
         m[e] = mv; v[e] = vv;
         p[e] -= step_size * mv / (sqrtf(vv) / bc2_sqrt + eps);
+    }
+}
+
+// out[i] = sum_z slabs[z*stride + i]
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int splits,
+                                                        int64_t count4, float4* __restrict__ out) {
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < count4; e += (int64_t)gridDim.x * 256) {
+        float4 s = reinterpret_cast<const float4*>(slabs)[e];
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(slabs + z * stride)[e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[e] = s;
     }
 }
 
@@ -267,6 +281,16 @@ __global__ __launch_bounds__(256) void chain_hprev_kernel(const float* __restric
 }  // namespace
 
 using icrl::as_stream;
+
+extern "C" int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
+                              icrl_stream_t stream) {
+    ICRL_REQUIRE(slabs && out && splits >= 1 && count > 0 && count % 4 == 0 && slab_stride % 4 == 0,
+                 "icrl_sum_slabs: bad argument");
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(count / 4, 256)), dim3(256), 0, as_stream(stream), slabs,
+                       slab_stride, splits, count / 4, reinterpret_cast<float4*>(out));
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
 
 extern "C" int icrl_gather_rows(const float* table, int width, const int64_t* idx, int64_t idx_stride,
                                 int rows, float* out, icrl_stream_t stream) {
@@ -346,24 +370,25 @@ extern "C" int icrl_a2c_loss(const float* values, const float* rewards, const fl
     return ICRL_OK;
 }
 
-extern "C" int icrl_policy_dlogits(float* probs_inout, int rows, int V, const int64_t* tokens,
+extern "C" int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, const int64_t* tokens,
                                    int64_t token_stride, const float* coef, icrl_stream_t stream) {
-    ICRL_REQUIRE(probs_inout && tokens && coef && rows > 0 && V > 0,
+    ICRL_REQUIRE(probs && dlogits && tokens && coef && rows > 0 && V > 0,
                  "icrl_policy_dlogits: null pointer or empty shape");
     hipLaunchKernelGGL(policy_dlogits_kernel, dim3(grid_for((int64_t)rows * V, 256)), dim3(256), 0,
-                       as_stream(stream), probs_inout, rows, V, tokens, token_stride, coef);
+                       as_stream(stream), probs, dlogits, rows, V, tokens, token_stride, coef);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
 
 extern "C" int icrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                              float lr, float beta1, float beta2, float eps, int step,
+                              double lr, double beta1, double beta2, double eps, int step,
                               icrl_stream_t stream) {
     ICRL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0,
                  "icrl_adam_step: null pointer, n <= 0 or step <= 0");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), param, grad,
-                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       exp_avg, exp_avg_sq, n, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), (float)eps, (float)bc1, (float)sqrt(bc2));
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

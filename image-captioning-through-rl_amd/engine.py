@@ -14,6 +14,15 @@ reference's Python loop; it computes the same numbers in a different order:
   3. loss (trainers.py:471-475), then the policy BPTT on one stream beside the value
      chain's BPTT on the other.
 
+The two recurrences can be evaluated in two ways (``chain_mode``):
+  * "exact": the persistent kernels of chain.hip walk the ~10^5 dependent steps one by one;
+  * "segmented": chain_seg.hip cuts the chain into segments that run side by side after a
+    warm-up, and reports how far each segment's warmed-up state was from the true state at
+    its seam.  The step is accepted only if every seam agrees to rounding level; otherwise
+    it is redone with a longer warm-up and finally with the exact kernels, so the result
+    never depends on the recurrence forgetting fast enough;
+  * "auto" (default): segmented for chains of at least 8192 positions, else exact.
+
 All device memory is PyTorch-owned and cached per problem shape; nothing here touches
 the CPU oracle, and every kernel call raises if libicrl_a2c.so is missing.
 """
@@ -28,9 +37,10 @@ class A2CStepResult:
     """Device tensors of one minibatch.  tokens [N, p0+S] int64; log_probs, values,
     rewards [N, S] float32; scalars[0..4] = loss, actor, critic, mean reward, mean adv."""
 
-    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status):
+    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status, chain_plan=None):
         self.tokens, self.log_probs, self.values, self.rewards = tokens, log_probs, values, rewards
         self.scalars, self.entropy, self.status = scalars, entropy, status
+        self.chain_plan = chain_plan  # ("exact",) or ("segmented", segments, warmup) that produced it
 
     def check(self):
         """Synchronises; raises if a chain kernel gave up waiting for a peer workgroup."""
@@ -41,14 +51,22 @@ class A2CStepResult:
 
 
 class A2CEngine:
+    SEAM_TOL_FWD = 1e-5   # max |state_warm - state_true| / max(1, |state_true|) over h and c
+    SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
+
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
-                 concurrent=True):
+                 concurrent=True, chain_mode="auto", segments=None, warmups=(96, 192, 384)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
         missing from the grads dicts (e.g. frozen pretrained embeddings) get no gradient."""
         self.P, self.V, self.R = policy_params, value_params, reward_params
         self.gP, self.gV = policy_grads or {}, value_grads or {}
         self.concurrent = concurrent
+        assert chain_mode in ("auto", "exact", "segmented")
+        self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
+        self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
+        self._first_plan = 0  # plans that failed once are not tried first again (parameters drift slowly)
+        self.last_seam = None
         self._ws = {}
         self._side = None
         dev = self.P["cnn2linear.weight"].device
@@ -92,10 +110,30 @@ class A2CEngine:
             dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev),
             dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
             dX=f32(t_steps * n, e), tv=tv,
+            seam=torch.zeros(6, dtype=torch.float32, device=dev), dlogits=f32(s, n, v),
+            whh_slabs=f32(8, 4 * H, H),
         )
+        k = self._segments_for(tv)
+        if k:
+            ws["work_v"] = f32(hip.chain_seg_workspace_floats(k))
+            ws["work_r"] = f32(hip.chain_seg_workspace_floats(k))
+        ws["segments"] = k
         ws["Cbuf"][0].zero_()
         self._ws[key] = ws
         return ws
+
+    def _segments_for(self, positions):
+        """Number of segments for a chain of `positions` steps; 0 = use the exact kernels."""
+        if self.chain_mode == "exact" or (self.chain_mode == "auto" and positions < 8192):
+            return 0
+        if self.segments:
+            return int(self.segments)
+        return max(2, min(512, positions // 128))
+
+    def _plans(self, ws):
+        k = ws["segments"]
+        plans = [("segmented", k, w) for w in self.warmups] if k else []
+        return plans + [("exact",)]
 
     def _side_stream(self):
         if self._side is None:
@@ -139,18 +177,44 @@ class A2CEngine:
                                   uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
                                   log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
                                   entropy=ws["entropy"][st] if mode != hip.GREEDY else None)
-        tok_flat = tokT.view(-1)
+        side = self._side_stream() if self.concurrent else main
+        plans = self._plans(ws)
+        start = min(self._first_plan, len(plans) - 1)
+        for attempt, plan in enumerate(plans[start:], start):
+            self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, plan)
+            if plan[0] == "exact":
+                break
+            seam = ws["seam"].tolist()  # host sync; the caller synchronises per step anyway
+            self.last_seam = seam
+            ok = (seam[0] <= self.SEAM_TOL_FWD and seam[2] <= self.SEAM_TOL_FWD
+                  and (not backward or mode == hip.GREEDY or seam[4] <= self.SEAM_TOL_BWD * seam[5] + 1e-30))
+            if ok:
+                break
+            self.fallbacks += 1
+            self._first_plan = attempt + 1
+        return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
+                             ws["rewards"].view(s, n).t().contiguous(), ws["scalars"], ws["entropy"], ws["status"],
+                             plan)
+
+    def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan):
+        P, V, R = self.P, self.V, self.R
+        t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
+        tok_flat = ws["tokT"].view(-1)
+        seg = plan[0] == "segmented"
 
         # ---- 2. reward GRU chain on the side stream, value LSTM chain on the main stream
-        side = self._side_stream() if self.concurrent else main
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev_tok)
             hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["XPr"],
                      a_rows=tok_flat[:l_cols * n], bias=R["rewrnn.gru.bias_ih_l0"])
-            hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
-                              ws["hr"], ws["sync_r"], ws["status"][1:2])
+            if seg:
+                hip.gru_chain_fwd_seg(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
+                                      plan[1], plan[2], ws["hr"], ws["work_r"], ws["seam"][2:4])
+            else:
+                hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
+                                  ws["hr"], ws["sync_r"], ws["status"][1:2])
             hip.gemm(ws["hr"].view(s * n, H), R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
             hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
             hip.cosine_reward(ws["ve"], ws["se"], s * n, n, ws["rewards"])
@@ -159,8 +223,12 @@ class A2CEngine:
         hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
         hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
                  bias2=V["valrnn.lstm.bias_hh_l0"])
-        hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, ws["hv"],
-                           ws["saved"] if backward else None, ws["sync_v"], ws["status"][0:1])
+        if seg:
+            hip.lstm_chain_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, plan[1], plan[2], ws["hv"],
+                                   ws["saved"] if backward else None, ws["work_v"], ws["seam"][0:2])
+        else:
+            hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, ws["hv"],
+                               ws["saved"] if backward else None, ws["sync_v"], ws["status"][0:1])
         w1 = V["linear1.weight"]
         hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
         hip.gemm(ws["hv"].view(s * n, H), w1[:, self.F:], ws["Y"])
@@ -171,13 +239,10 @@ class A2CEngine:
         hip.a2c_loss(ws["values"], ws["rewards"], ws["logp"].view(-1), ws["scalars"],
                      ws["dvalue"] if backward else None, ws["dlogp"] if backward else None)
         if backward and mode != hip.GREEDY:
-            self._backward(ws, features, n, p0, s, main, side)
-
-        return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
-                             ws["rewards"].view(s, n).t().contiguous(), ws["scalars"], ws["entropy"], ws["status"])
+            self._backward(ws, features, n, p0, s, main, side, plan)
 
     # ------------------------------------------------------------------ gradients
-    def _backward(self, ws, features, n, p0, s, main, side):
+    def _backward(self, ws, features, n, p0, s, main, side, plan):
         P, V = self.P, self.V
         gP, gV = self.gP, self.gV
         t_steps, lv, tv = p0 - 1 + s, p0 + s - 1, ws["tv"]
@@ -197,8 +262,12 @@ class A2CEngine:
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
         hip.colsum(dY, gV["linear1.bias"])
         hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
-        hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
-                           ws["sync_v"], ws["status"][2:3])
+        if plan[0] == "segmented":
+            hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, plan[1], plan[2],
+                                   ws["dgv"], ws["work_v"], ws["seam"][4:6])
+        else:
+            hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
+                               ws["sync_v"], ws["status"][2:3])
 
         # ---- policy network BPTT on the side stream, beside the value chain
         with torch.cuda.stream(side):
@@ -209,7 +278,11 @@ class A2CEngine:
 
         # ---- value network: weight gradients from the chain's gate gradients
         hip.chain_hprev(ws["saved"], tv, ws["hprev"])
-        hip.gemm(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], a_kmajor=True, b_kmajor=True)
+        if tv >= 16384:  # long k, small output: split-K partial slabs, summed in a fixed order
+            hip.gemm_splitk(ws["dgv"], ws["hprev"], ws["whh_slabs"], 8, a_kmajor=True, b_kmajor=True)
+            hip.sum_slabs(ws["whh_slabs"], gV["valrnn.lstm.weight_hh_l0"])
+        else:
+            hip.gemm(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], a_kmajor=True, b_kmajor=True)
         hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])
         hip.gemm(ws["dGsum"], ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], a_kmajor=True, b_kmajor=True)
         hip.colsum(ws["dGsum"], gV["valrnn.lstm.bias_ih_l0"])
@@ -225,8 +298,8 @@ class A2CEngine:
         P, gP = self.P, self.gP
         t_steps = p0 - 1 + s
         tok_flat = ws["tokT"].view(-1)
-        G = ws["probs"].view(s * n, self.vocab)
-        hip.policy_dlogits(G, tok_flat[p0 * n:], 1, ws["dlogp"])
+        G = ws["dlogits"].view(s * n, self.vocab)
+        hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G, tok_flat[p0 * n:], 1, ws["dlogp"])
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
         hip.gemm(G, Hs, gP["linear2vocab.weight"], a_kmajor=True, b_kmajor=True)
         hip.colsum(G, gP["linear2vocab.bias"])

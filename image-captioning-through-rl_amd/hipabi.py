@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libicrl_a2c.so")
 
-c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+c_int, c_i64, c_f32, c_f64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 # name -> (restype, argtypes); mirrors include/icrl_a2c.h one to one
 SIGNATURES = {
@@ -21,6 +21,13 @@ SIGNATURES = {
     "icrl_last_error": (ctypes.c_char_p, []),
     "icrl_gemm_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int,
                               c_vp, c_vp, c_int, c_vp]),
+    "icrl_gemm_f32_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
+                                     c_int, c_vp]),
+    "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
+    "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
+    "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_lstm_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
@@ -28,7 +35,7 @@ SIGNATURES = {
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                                    c_vp]),
-    "icrl_policy_dlogits": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
+    "icrl_policy_dlogits": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "icrl_chain_sync_bytes": (c_i64, []),
     "icrl_lstm_chain_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gru_chain_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -38,7 +45,7 @@ SIGNATURES = {
     "icrl_value_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_cosine_reward": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_a2c_loss": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
+    "icrl_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f64, c_f64, c_f64, c_f64, c_int, c_vp]),
 }
 
 SAMPLE, GREEDY, FORCED = 0, 1, 2
@@ -190,9 +197,9 @@ def sample_tokens(logits, mode, tokens_out, token_stride, *, uniforms=None, log_
                                      _stream()), "icrl_sample_tokens")
 
 
-def policy_dlogits(probs_inout, tokens, token_stride, coef):
-    rows, v = probs_inout.shape
-    _check(load().icrl_policy_dlogits(_ptr(_f32c(probs_inout)), rows, v, _ptr(tokens), token_stride,
+def policy_dlogits(probs, dlogits, tokens, token_stride, coef):
+    rows, v = probs.shape
+    _check(load().icrl_policy_dlogits(_ptr(_f32c(probs)), _ptr(_f32c(dlogits)), rows, v, _ptr(tokens), token_stride,
                                       _ptr(_f32c(coef)), _stream()), "icrl_policy_dlogits")
 
 
@@ -253,3 +260,50 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     _check(load().icrl_adam_step(_ptr(_f32c(param)), _ptr(_f32c(grad)), _ptr(_f32c(exp_avg)),
                                  _ptr(_f32c(exp_avg_sq)), param.numel(), lr, beta1, beta2, eps, step, _stream()),
            "icrl_adam_step")
+
+
+def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False):
+    """slabs[z] = partial product of split z; slabs is [splits, M, N] contiguous."""
+    m = a.shape[1] if a_kmajor else a.shape[0]
+    k = a.shape[0] if a_kmajor else a.shape[1]
+    n = b.shape[1] if b_kmajor else b.shape[0]
+    assert slabs.shape == (splits, m, n) and slabs.is_contiguous()
+    with _Timed("gemm", 2.0 * m * n * k):
+        rc = load().icrl_gemm_f32_splitk(_ptr(a), a.stride(0), int(a_kmajor), _ptr(b), b.stride(0), int(b_kmajor),
+                                         _ptr(slabs), n, m * n, m, n, k, splits, _stream())
+    _check(rc, "icrl_gemm_f32_splitk")
+
+
+def sum_slabs(slabs, out):
+    splits = slabs.shape[0]
+    count = slabs[0].numel()
+    assert out.is_contiguous() and out.numel() == count
+    _check(load().icrl_sum_slabs(_ptr(_f32c(slabs)), count, splits, count, _ptr(out), _stream()), "icrl_sum_slabs")
+
+
+def chain_seg_workspace_floats(segments):
+    return int(load().icrl_chain_seg_workspace_floats(segments))
+
+
+def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, work, seam_err):
+    with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
+        rc = load().icrl_lstm_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, segments, warmup,
+                                            _ptr(_f32c(h_emit)), _ptr(saved), _ptr(_f32c(work)), _ptr(seam_err),
+                                            _stream())
+    _check(rc, "icrl_lstm_chain_fwd_seg")
+
+
+def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err):
+    with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
+        rc = load().icrl_gru_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
+                                           segments, warmup, _ptr(_f32c(h_emit)), _ptr(_f32c(work)), _ptr(seam_err),
+                                           _stream())
+    _check(rc, "icrl_gru_chain_fwd_seg")
+
+
+def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err):
+    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
+        rc = load().icrl_lstm_chain_bwd_seg(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
+                                            n_calls, segments, warmup, _ptr(_f32c(dgates)), _ptr(_f32c(work)),
+                                            _ptr(seam_err), _stream())
+    _check(rc, "icrl_lstm_chain_bwd_seg")

@@ -100,11 +100,11 @@ def _grads_of(module):
     return grads
 
 
-def build_engine(a2c_network, reward_network, concurrent=True):
+def build_engine(a2c_network, reward_network, **engine_options):
     """Bind an A2CEngine to the live parameter / gradient storage of the modules."""
     return A2CEngine(_params_of(a2c_network.policy_network), _params_of(a2c_network.value_network),
                      _params_of(reward_network), _grads_of(a2c_network.policy_network),
-                     _grads_of(a2c_network.value_network), concurrent=concurrent)
+                     _grads_of(a2c_network.value_network), **engine_options)
 
 
 def caption_length(captions):

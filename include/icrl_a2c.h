@@ -52,6 +52,19 @@ int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_ro
                   int M, int N, int K, const float* bias, const float* bias2,
                   int accumulate, icrl_stream_t stream);
 
+/* Split-K form for products with a long k and a small output (the weight gradients
+ * summed over ~10^5 chain positions; the per-step products of the segment-parallel chain):
+ * split z in [0, splits) writes its partial product over its k-range to
+ * C_slabs + z*slab_stride; the consumer adds the slabs (fixed order, so results are
+ * reproducible run to run, unlike float atomics). */
+int icrl_gemm_f32_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
+                         int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
+                         int N, int K, int splits, icrl_stream_t stream);
+
+/* out[i] = sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
+int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
+                   icrl_stream_t stream);
+
 /* out[r, :] = table[idx[r*idx_stride], :]   (nn.Embedding, models.py:73, 132, 225) */
 int icrl_gather_rows(const float* table, int width, const int64_t* idx, int64_t idx_stride,
                      int rows, float* out, icrl_stream_t stream);
@@ -94,9 +107,9 @@ int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int
                        float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
                        icrl_stream_t stream);
 
-/* d logits for the policy-gradient term, in place over the saved softmax:
+/* d logits for the policy-gradient term from the saved softmax (dlogits may alias probs):
  * g[r, k] = coef[r] * ((k == token[r]) - p[r, k]),  coef = dLoss/dlog_prob. */
-int icrl_policy_dlogits(float* probs_inout, int rows, int V, const int64_t* tokens,
+int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, const int64_t* tokens,
                         int64_t token_stride, const float* coef, icrl_stream_t stream);
 
 /* ---- batch-1 recurrent chains (models.py:130-135, 166-169; :223-228, 253-255) -
@@ -134,6 +147,30 @@ int icrl_gru_chain_fwd(const float* xproj, const float* w_hh, const float* b_hh,
 int icrl_lstm_chain_bwd(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
                         int n_calls, float* dgates, void* sync_ws, int32_t* status,
                         icrl_stream_t stream);
+/* ---- the same chains, segment-parallel with a seam check ------------------------
+ * A gated recurrence forgets its initial state, so the chain is cut into `segments`
+ * pieces that run side by side: each piece first runs `warmup` extra steps over the
+ * positions before its start (after its end, for the backward pass) from a zero state.
+ * Every step of all pieces is one [segments,512] x W_hh product on the matrix cores plus
+ * a fused cell kernel.  Nothing is assumed about the forgetting rate: the state each
+ * piece reached after its warm-up is compared with the state its neighbour really ended
+ * in, and the worst mismatch is reported in seam_err (forward: seam_err[0] = max
+ * |a-b|/max(1,|b|) over h and c; backward: seam_err[0] = max |a-b|, seam_err[1] = max |b|
+ * over dh and dc).  The caller accepts the result only when that is at rounding level and
+ * otherwise reruns with a longer warm-up or the exact kernels above.  Same inputs,
+ * outputs and layouts as icrl_lstm_chain_fwd / icrl_gru_chain_fwd / icrl_lstm_chain_bwd
+ * (zero initial state); work = icrl_chain_seg_workspace_floats(segments) floats. */
+int64_t icrl_chain_seg_workspace_floats(int segments);
+int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+                            int segments, int warmup, float* h_emit, float* saved, float* work,
+                            float* seam_err, icrl_stream_t stream);
+int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
+                           int n_calls, int segments, int warmup, float* h_emit, float* work,
+                           float* seam_err, icrl_stream_t stream);
+int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                            int n_calls, int segments, int warmup, float* dgates, float* work,
+                            float* seam_err, icrl_stream_t stream);
+
 /* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
 int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
                           icrl_stream_t stream);
@@ -161,7 +198,7 @@ int icrl_a2c_loss(const float* values, const float* rewards, const float* log_pr
 
 /* ---- Adam (trainers.py:378, 480): torch.optim.Adam defaults, bias-corrected ---- */
 int icrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                   float lr, float beta1, float beta2, float eps, int step,
+                   double lr, double beta1, double beta2, double eps, int step,
                    icrl_stream_t stream);
 
 #ifdef __cplusplus

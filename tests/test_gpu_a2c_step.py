@@ -211,3 +211,53 @@ def test_module_forwards_carry_hidden_state_like_the_reference():
 def test_bidirectional_is_rejected_loudly():
     with pytest.raises(NotImplementedError):
         models.PolicyNetwork({"a": 0, "b": 1}, bidirectional=True)
+
+
+def _grads(a2c):
+    return {k: p.grad.clone() for k, p in a2c.named_parameters()}
+
+
+def _step_with(a2c, rew, feats, caps, steps, u, **opts):
+    engine = trainers.build_engine(a2c, rew, **opts)
+    res = engine.step(torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :1]).cuda(), steps,
+                      uniforms=torch.from_numpy(u).cuda()).check()
+    torch.cuda.synchronize()
+    return engine, res, _grads(a2c)
+
+
+def test_segmented_chains_give_the_exact_step():
+    """Segment-parallel chains (accepted by their seam check) vs the exact persistent
+    kernels on the same minibatch: every output and gradient, GPU against GPU."""
+    cfg = dict(n=64, vocab=500, caplen=14, fdim=2048, seed=3, level=None)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(64, 500, 14, 2048, 3)
+    u = synthetic.make_uniforms(3, 13 * 64)
+    _, exact, g_exact = _step_with(a2c, rew, feats, caps, 13, u, chain_mode="exact")
+    assert exact.chain_plan == ("exact",)
+    eng, seg, g_seg = _step_with(a2c, rew, feats, caps, 13, u, chain_mode="segmented", segments=24, warmups=(96,))
+    assert seg.chain_plan == ("segmented", 24, 96) and eng.fallbacks == 0
+    assert torch.equal(seg.tokens, exact.tokens)
+    np.testing.assert_allclose(seg.values.cpu().numpy(), exact.values.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(seg.rewards.cpu().numpy(), exact.rewards.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(seg.scalars.cpu().numpy()[:5], exact.scalars.cpu().numpy()[:5], rtol=1e-5, atol=1e-7)
+    for k in g_exact:
+        scale = g_exact[k].pow(2).mean().sqrt().item() + 1e-12
+        assert (g_seg[k] - g_exact[k]).abs().max().item() <= 1e-3 * scale + 1e-9, k
+
+
+def test_seam_check_rejects_and_falls_back_to_the_exact_kernels():
+    """A value LSTM that remembers (forget gates pinned near 1) with a 2-step warm-up:
+    the seam check must refuse the segmented result and the step must still be exact."""
+    cfg = dict(n=32, vocab=200, caplen=10, fdim=512, seed=4, level=None)
+    a2c, rew = build_modules(cfg)
+    with torch.no_grad():
+        a2c.value_network.valrnn.lstm.bias_ih_l0[512:1024] += 8.0
+    feats, caps = synthetic.make_minibatch(32, 200, 10, 512, 4)
+    u = synthetic.make_uniforms(4, 9 * 32)
+    _, exact, g_exact = _step_with(a2c, rew, feats, caps, 9, u, chain_mode="exact")
+    eng, seg, g_seg = _step_with(a2c, rew, feats, caps, 9, u, chain_mode="segmented", segments=8, warmups=(2,))
+    assert eng.fallbacks == 1 and seg.chain_plan == ("exact",)
+    assert torch.equal(seg.values, exact.values)
+    for k in g_exact:
+        scale = g_exact[k].pow(2).mean().sqrt().item() + 1e-12
+        assert (g_seg[k] - g_exact[k]).abs().max().item() <= 1e-4 * scale + 1e-9, k

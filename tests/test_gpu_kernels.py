@@ -150,7 +150,7 @@ def test_policy_dlogits_loss_value_head_cosine_adam():
     toks = rs.randint(0, v, size=rows).astype(np.int64)
     coef = rnd(rs, rows)
     g = dev(p)
-    hip.policy_dlogits(g, dev(toks, torch.int64), 1, dev(coef))
+    hip.policy_dlogits(g, g, dev(toks, torch.int64), 1, dev(coef))
     hot = np.zeros((rows, v)); hot[np.arange(rows), toks] = 1
     np.testing.assert_allclose(g.cpu().numpy(), coef[:, None] * (hot - p), rtol=1e-6, atol=1e-8)
 
@@ -285,3 +285,72 @@ def test_chain_long_run_is_stable_and_timed():
     hip.lstm_chain_fwd(xd, wd, n, p0, calls, h_emit, saved, ws, status)
     torch.cuda.synchronize()
     assert torch.equal(saved, saved2)
+
+
+# --------------------------------------------------------------------------- segment-parallel chains
+def _seg_ws(k):
+    return (torch.zeros(hip.chain_seg_workspace_floats(k), device="cuda"), torch.zeros(2, device="cuda"))
+
+
+@pytest.mark.parametrize("n,p0,calls,segs,warm", [(64, 1, 19, 32, 64), (16, 3, 6, 7, 40), (64, 1, 19, 512, 64)])
+def test_segmented_chains_match_the_exact_kernels(n, p0, calls, segs, warm):
+    rs = np.random.RandomState(segs)
+    cols = p0 + calls
+    positions = n * sum(p0 + s for s in range(calls))
+    xproj, w_hh = _chain_inputs(rs, n, cols, 4)
+    xd, wd = dev(xproj), dev(w_hh)
+    d_emit = dev(rnd(rs, calls, n, H))
+    ws, status = _ws()
+    h_x, saved_x = torch.zeros(calls, n, H, device="cuda"), torch.zeros(positions, 6, H, device="cuda")
+    dg_x = torch.zeros(positions, 4 * H, device="cuda")
+    hip.lstm_chain_fwd(xd, wd, n, p0, calls, h_x, saved_x, ws, status)
+    hip.lstm_chain_bwd(wd, saved_x, d_emit, n, p0, calls, dg_x, ws, status)
+    work, err = _seg_ws(segs)
+    h_s, saved_s = torch.zeros_like(h_x), torch.zeros_like(saved_x)
+    dg_s = torch.zeros_like(dg_x)
+    hip.lstm_chain_fwd_seg(xd, wd, n, p0, calls, segs, warm, h_s, saved_s, work, err)
+    torch.cuda.synchronize()
+    assert status.item() == 0
+    assert err[0].item() < 2e-6, "seam check: warm-up state differs from the true state"
+    np.testing.assert_allclose(saved_s.cpu().numpy(), saved_x.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(h_s.cpu().numpy(), h_x.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    hip.lstm_chain_bwd_seg(wd, saved_x, d_emit, n, p0, calls, segs, warm, dg_s, work, err)
+    torch.cuda.synchronize()
+    assert err[0].item() <= 1e-5 * err[1].item() + 1e-12
+    scale = dg_x.abs().max().item()
+    assert (dg_s - dg_x).abs().max().item() <= 2e-5 * scale
+    # GRU (reward network): p0+1 columns in the first call
+    xg, wg = _chain_inputs(rs, n, cols, 3)
+    bg = dev(rnd(rs, 3 * H, scale=0.1))
+    g_x, g_s = torch.zeros(calls, n, H, device="cuda"), torch.zeros(calls, n, H, device="cuda")
+    hip.gru_chain_fwd(dev(xg), dev(wg), bg, n, p0 + 1, calls, g_x, ws, status)
+    hip.gru_chain_fwd_seg(dev(xg), dev(wg), bg, n, p0 + 1, calls, segs, warm, g_s, work, err)
+    torch.cuda.synchronize()
+    assert status.item() == 0 and err[0].item() < 2e-6
+    np.testing.assert_allclose(g_s.cpu().numpy(), g_x.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_seam_check_detects_a_chain_that_has_not_forgotten():
+    """Forget gates pinned near 1 and a warm-up of 2 steps: the seam error must say so."""
+    rs = np.random.RandomState(9)
+    n, p0, calls, segs = 32, 1, 8, 8
+    xproj, w_hh = _chain_inputs(rs, n, p0 + calls, 4)
+    xproj[:, H:2 * H] += 8.0  # forget-gate pre-activation
+    work, err = _seg_ws(segs)
+    positions = n * sum(p0 + s for s in range(calls))
+    h_s, saved_s = torch.zeros(calls, n, H, device="cuda"), torch.zeros(positions, 6, H, device="cuda")
+    hip.lstm_chain_fwd_seg(dev(xproj), dev(w_hh), n, p0, calls, segs, 2, h_s, saved_s, work, err)
+    torch.cuda.synchronize()
+    assert err[0].item() > 1e-2
+
+
+def test_splitk_gemm_and_slab_sum():
+    rs = np.random.RandomState(12)
+    m, n, k, splits = 200, 96, 5000, 7
+    a, b = rnd(rs, k, m), rnd(rs, k, n)
+    slabs = torch.zeros(splits, m, n, device="cuda")
+    hip.gemm_splitk(dev(a), dev(b), slabs, splits, a_kmajor=True, b_kmajor=True)
+    out = torch.zeros(m, n, device="cuda")
+    hip.sum_slabs(slabs, out)
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-3)
