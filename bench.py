@@ -104,7 +104,8 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
-    if world > 1:
+    ddp.broadcast_parameters(flat.flat)
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     hip.PROFILE = []
@@ -112,7 +113,7 @@ def main():
     for i in range(args.steps):
         res = one_step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
     elapsed = ddp.max_over_ranks(time.perf_counter() - t0, dev)
     prof, hip.PROFILE = hip.PROFILE, None
@@ -164,7 +165,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(syn, params, vocab, caplen, fdim, args.cpu_sample_batch)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

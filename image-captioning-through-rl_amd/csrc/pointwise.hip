@@ -43,21 +43,24 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict
     }
 }
 
-// out[n] (+)= sum_r x[r, n]; one workgroup per 64 columns, 4 waves stride the rows.
+// out[n] (+)= sum_r x[r, n]: workgroup (bx, by) sums 64 columns over its slice of the rows (4 waves
+// stride it) and adds its partial to out[] with one float atomic per column.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
-                                                     int cols, float* __restrict__ out, int accumulate) {
+                                                     int cols, int rows_per_block, float* __restrict__ out) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (col < cols)
-        for (int r = wave; r < rows; r += 4) s += x[(int64_t)r * ldx + col];
-    part[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && col < cols) {
-        const float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-        out[col] = accumulate ? out[col] + t : t;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    if (col < cols) {
+        int r = r0 + wave;
+        for (; r + 4 < r1; r += 8) { s0 += x[(int64_t)r * ldx + col]; s1 += x[(int64_t)(r + 4) * ldx + col]; }
+        if (r < r1) s0 += x[(int64_t)r * ldx + col];
     }
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && col < cols)
+        atomicAdd(out + col, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
 }
 
 // ---------------------------------------------------------------- batched LSTM cell
@@ -315,8 +318,15 @@ extern "C" int icrl_scatter_add_rows(float* grad_table, int width, const int64_t
 extern "C" int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
                            icrl_stream_t stream) {
     ICRL_REQUIRE(x && out && rows > 0 && cols > 0, "icrl_colsum: null pointer or empty shape");
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), x, ldx, rows,
-                       cols, out, accumulate);
+    hipStream_t st = as_stream(stream);
+    if (!accumulate) ICRL_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+    const int col_blocks = (cols + 63) / 64;
+    int row_blocks = 2048 / col_blocks;                   // aim at ~2048 workgroups
+    if (row_blocks > (rows + 63) / 64) row_blocks = (rows + 63) / 64;
+    if (row_blocks < 1) row_blocks = 1;
+    const int rows_per_block = (rows + row_blocks - 1) / row_blocks;
+    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, st, x, ldx, rows, cols,
+                       rows_per_block, out);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -19,16 +19,29 @@ def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun's env).
     Returns (rank, world, local_rank); a no-op (0, 1, 0) when WORLD_SIZE is unset or 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not _force_collectives():
         return 0, 1, 0
-    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _force_collectives():
+    """ICRL_FORCE_COLLECTIVES=1 makes a single-rank launch (under torch.distributed.run) initialise
+    the process group and issue every collective anyway: the N > 1 code path on one GPU."""
+    return os.environ.get("ICRL_FORCE_COLLECTIVES", "0") == "1" and "MASTER_ADDR" in os.environ
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force_collectives())
 
 
 def world_size():
@@ -37,16 +50,15 @@ def world_size():
 
 def average_gradients(flat_grad):
     """In-place mean over ranks of the flat gradient buffer (sum, then divide)."""
-    w = world_size()
-    if w > 1:
+    if _active():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-        flat_grad.div_(w)
+        flat_grad.div_(world_size())
     return flat_grad
 
 
 def broadcast_parameters(flat, src=0):
     """Make every rank start from rank `src`'s parameters."""
-    if world_size() > 1:
+    if _active():
         dist.broadcast(flat, src=src)
     return flat
 
@@ -54,7 +66,7 @@ def broadcast_parameters(flat, src=0):
 def max_over_ranks(value, device):
     """Max of a python float over ranks (bench timing)."""
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

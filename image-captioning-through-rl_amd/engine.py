@@ -65,6 +65,7 @@ class A2CEngine:
         assert chain_mode in ("auto", "exact", "segmented")
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
+        self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
         self._first_plan = 0  # plans that failed once are not tried first again (parameters drift slowly)
         self.last_seam = None
         self._ws = {}
@@ -135,6 +136,12 @@ class A2CEngine:
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
 
+    def _mark(self, label):
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            self.trace.append((label, ev))
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -162,6 +169,7 @@ class A2CEngine:
             assert uniforms is not None and uniforms.dtype == torch.float64 and uniforms.numel() >= s * n
         main = torch.cuda.current_stream()
 
+        self._mark("start")
         # ---- 1. policy rollout (models.py:71-84 run incrementally; trainers.py:443-458)
         Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
         hip.gemm(features, P["cnn2linear.weight"], Hb[0], bias=P["cnn2linear.bias"])
@@ -177,6 +185,7 @@ class A2CEngine:
                                   uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
                                   log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
                                   entropy=ws["entropy"][st] if mode != hip.GREEDY else None)
+        self._mark("rollout_done")
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
         start = min(self._first_plan, len(plans) - 1)
@@ -218,6 +227,7 @@ class A2CEngine:
             hip.gemm(ws["hr"].view(s * n, H), R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
             hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
             hip.cosine_reward(ws["ve"], ws["se"], s * n, n, ws["rewards"])
+            self._mark("side:reward_done")
             ev_rew = torch.cuda.Event()
             ev_rew.record(side)
         hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
@@ -233,13 +243,16 @@ class A2CEngine:
         hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
         hip.gemm(ws["hv"].view(s * n, H), w1[:, self.F:], ws["Y"])
         hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], s * n, n, ws["values"])
+        self._mark("value_fwd_done")
         main.wait_event(ev_rew)
 
         # ---- 3. loss (trainers.py:471-476)
         hip.a2c_loss(ws["values"], ws["rewards"], ws["logp"].view(-1), ws["scalars"],
                      ws["dvalue"] if backward else None, ws["dlogp"] if backward else None)
+        self._mark("loss_done")
         if backward and mode != hip.GREEDY:
             self._backward(ws, features, n, p0, s, main, side, plan)
+        self._mark("backward_done")
 
     # ------------------------------------------------------------------ gradients
     def _backward(self, ws, features, n, p0, s, main, side, plan):
@@ -269,10 +282,13 @@ class A2CEngine:
             hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
                                ws["sync_v"], ws["status"][2:3])
 
+        self._mark("value_chain_bwd_done")
         # ---- policy network BPTT on the side stream, beside the value chain
         with torch.cuda.stream(side):
             side.wait_event(ev_loss)
+            self._mark("side:policy_bwd_start")
             self._policy_backward(ws, features, n, p0, s)
+            self._mark("side:policy_bwd_done")
             ev_pol = torch.cuda.Event()
             ev_pol.record(side)
 
@@ -292,6 +308,7 @@ class A2CEngine:
             hip.gemm(ws["dGsum"], V["valrnn.lstm.weight_ih_l0"], ws["dXv"], b_kmajor=True)
             g_emb.zero_()
             hip.scatter_add_rows(g_emb, tok_flat, 1, lv * n, ws["dXv"])
+        self._mark("value_wgrads_done")
         main.wait_event(ev_pol)
 
     def _policy_backward(self, ws, features, n, p0, s):
