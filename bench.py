@@ -135,6 +135,17 @@ def main():
     fwd = 2 * fdim * h_dim + steps_per_rollout * (2 * (e_dim + h_dim) * 4 * h_dim + 2 * h_dim * vocab)
     policy_flops_per_image = 3 * fwd
     value = world * n * args.steps / elapsed
+    # MFMA work the segment-parallel chain kernels executed (warm-up steps included): per launch one
+    # [segments, 512] x [512, G*512] product; the chain events above time those launches
+    seg_flops = 0.0
+    plan = res.chain_plan
+    if plan[0] == "segmented":
+        _, segs, warm = plan
+        for kind, gates, p0 in (("lstm_chain_fwd", 4, 1), ("gru_chain_fwd", 3, 2), ("lstm_chain_bwd", 4, 1)):
+            positions = hip.chain_positions(n, p0, steps_per_rollout)
+            launches = warm + (positions + segs - 1) // segs
+            seg_flops += launches * 2.0 * segs * 512 * gates * 512
+    step_s = elapsed / args.steps
 
     if rank == 0:
         out = {
@@ -154,6 +165,12 @@ def main():
                          "gflop_per_step": gemm_flops / args.steps / 1e9,
                          "ms_per_step_in_kernel": 1e3 * gemm_s / args.steps},
             "chains": chains,
+            "mfma_work_of_whole_step": {
+                "gflop_executed_per_step": (gemm_flops / args.steps + seg_flops) / 1e9,
+                "achieved_tflops": (gemm_flops / args.steps + seg_flops) / step_s / 1e12,
+                "frac_of_f32_mfma_peak": (gemm_flops / args.steps + seg_flops) / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                "note": "all f32 MFMA FLOPs launched in a step (GEMM launches + segment-parallel chain steps, "
+                        "their warm-up included) over the step's wall time"},
             "lstm_gemm_roofline_of_whole_step": {
                 "policy_flops_per_image_fwd_bwd": policy_flops_per_image,
                 "achieved_tflops": policy_flops_per_image * value / world / 1e12,

@@ -220,6 +220,8 @@ int launch(const GemmArgs& g, int a_km, int b_km, int splits, hipStream_t st) {
 }  // namespace
 
 namespace {
+int g_forced_tile = 0;
+
 int gemm_dispatch(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows, const float* B, int64_t ldb,
                   int b_kmajor, float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2,
                   int accumulate, int splits, int64_t slab, hipStream_t st, const char* who) {
@@ -238,10 +240,21 @@ int gemm_dispatch(const float* A, int64_t lda, int a_kmajor, const int64_t* a_ro
     g.kchunk = ((ksteps + splits - 1) / splits) * BK;
     g.slab = slab;
     const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits;
-    if (big_tiles >= 256) return launch<128, 128>(g, a_kmajor, b_kmajor, splits, st);
+    int tile = g_forced_tile;
+    if (tile == 0) tile = (big_tiles >= 256 && K > 1024) ? 2 : 3;  // measured: 64x64 wins for short k loops
+    if (tile == 1) return launch<128, 128>(g, a_kmajor, b_kmajor, splits, st);
+    if (tile == 2) return launch<128, 64>(g, a_kmajor, b_kmajor, splits, st);
     return launch<64, 64>(g, a_kmajor, b_kmajor, splits, st);
 }
 }  // namespace
+
+// Tuning hook: 0 = choose by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64 output tiles.
+extern "C" int icrl_gemm_force_tile(int tile) {
+    ICRL_REQUIRE(tile >= 0 && tile <= 3, "icrl_gemm_force_tile: tile must be 0..3");
+    g_forced_tile = tile;
+    return ICRL_OK;
+}
+
 
 namespace icrl {
 // Used by the host-side chain schedules in this library.

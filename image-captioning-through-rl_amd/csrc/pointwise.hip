@@ -233,12 +233,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // out[i] = sum_z slabs[z*stride + i]
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, int64_t stride, int splits,
-                                                        int64_t count4, float4* __restrict__ out) {
+                                                        int64_t count4, float4* __restrict__ out, int accumulate) {
     for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < count4; e += (int64_t)gridDim.x * 256) {
         float4 s = reinterpret_cast<const float4*>(slabs)[e];
         for (int z = 1; z < splits; ++z) {
             const float4 v = reinterpret_cast<const float4*>(slabs + z * stride)[e];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (accumulate) {
+            const float4 o = out[e];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
         out[e] = s;
     }
@@ -286,11 +290,11 @@ __global__ __launch_bounds__(256) void chain_hprev_kernel(const float* __restric
 using icrl::as_stream;
 
 extern "C" int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
-                              icrl_stream_t stream) {
+                              int accumulate, icrl_stream_t stream) {
     ICRL_REQUIRE(slabs && out && splits >= 1 && count > 0 && count % 4 == 0 && slab_stride % 4 == 0,
                  "icrl_sum_slabs: bad argument");
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(count / 4, 256)), dim3(256), 0, as_stream(stream), slabs,
-                       slab_stride, splits, count / 4, reinterpret_cast<float4*>(out));
+                       slab_stride, splits, count / 4, reinterpret_cast<float4*>(out), accumulate);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -55,7 +55,8 @@ class A2CEngine:
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
 
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
-                 concurrent=True, chain_mode="auto", segments=None, warmups=(96, 192, 384)):
+                 concurrent=True, chain_mode="auto", segments=None,
+                 warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
         missing from the grads dicts (e.g. frozen pretrained embeddings) get no gradient."""
@@ -112,7 +113,8 @@ class A2CEngine:
             dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
             dX=f32(t_steps * n, e), tv=tv,
             seam=torch.zeros(6, dtype=torch.float32, device=dev), dlogits=f32(s, n, v),
-            whh_slabs=f32(8, 4 * H, H),
+            scratch_main=f32(max(16 * 4 * H * H, 2 * s * n * H, 3 * v * H)),
+            scratch_side=f32(max(16 * 4 * H * H, 2 * s * n * H, 3 * v * H)),
         )
         k = self._segments_for(tv)
         if k:
@@ -135,6 +137,26 @@ class A2CEngine:
         k = ws["segments"]
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
+
+    def _next_plan(self, plans, attempt, seam, with_bwd):
+        """After a rejected attempt: the seam error shrinks geometrically with the warm-up length
+        (from an O(1) initial mismatch), so estimate the length that reaches a tenth of the
+        tolerance and jump to the first plan at least that long."""
+        import math
+        w = plans[attempt][2]
+        need = w + 1
+        checks = [(seam[0], self.SEAM_TOL_FWD), (seam[2], self.SEAM_TOL_FWD)]
+        if with_bwd and seam[5] > 0:
+            checks.append((seam[4] / seam[5], self.SEAM_TOL_BWD))
+        for err, tol in checks:
+            if err > tol and 0 < err < 0.5:
+                need = max(need, int(math.ceil(w * math.log(tol / 10.0) / math.log(err))))
+            elif err >= 0.5 or err != err:
+                need = max(need, 4 * w)
+        for idx in range(attempt + 1, len(plans)):
+            if plans[idx][0] == "exact" or plans[idx][2] >= need:
+                return idx
+        return len(plans) - 1
 
     def _mark(self, label):
         if self.trace is not None:
@@ -188,19 +210,21 @@ class A2CEngine:
         self._mark("rollout_done")
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
-        start = min(self._first_plan, len(plans) - 1)
-        for attempt, plan in enumerate(plans[start:], start):
+        idx = min(self._first_plan, len(plans) - 1)
+        while True:
+            plan = plans[idx]
             self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, plan)
             if plan[0] == "exact":
                 break
             seam = ws["seam"].tolist()  # host sync; the caller synchronises per step anyway
             self.last_seam = seam
+            with_bwd = backward and mode != hip.GREEDY
             ok = (seam[0] <= self.SEAM_TOL_FWD and seam[2] <= self.SEAM_TOL_FWD
-                  and (not backward or mode == hip.GREEDY or seam[4] <= self.SEAM_TOL_BWD * seam[5] + 1e-30))
+                  and (not with_bwd or seam[4] <= self.SEAM_TOL_BWD * seam[5] + 1e-30))
             if ok:
                 break
             self.fallbacks += 1
-            self._first_plan = attempt + 1
+            idx = self._first_plan = self._next_plan(plans, idx, seam, with_bwd)
         return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                              ws["rewards"].view(s, n).t().contiguous(), ws["scalars"], ws["entropy"], ws["status"],
                              plan)
@@ -283,33 +307,39 @@ class A2CEngine:
                                ws["sync_v"], ws["status"][2:3])
 
         self._mark("value_chain_bwd_done")
-        # ---- policy network BPTT on the side stream, beside the value chain
+        ev_chain = torch.cuda.Event()
+        ev_chain.record(main)
+        # ---- side stream: the shifted h stream (needs only forward results), the policy network's BPTT
+        # beside the value chain, then the value network's input-side gradients once the chain is done
         with torch.cuda.stream(side):
             side.wait_event(ev_loss)
+            hip.chain_hprev(ws["saved"], tv, ws["hprev"])
+            ev_hprev = torch.cuda.Event()
+            ev_hprev.record(side)
             self._mark("side:policy_bwd_start")
             self._policy_backward(ws, features, n, p0, s)
             self._mark("side:policy_bwd_done")
-            ev_pol = torch.cuda.Event()
-            ev_pol.record(side)
+            side.wait_event(ev_chain)
+            ss = ws["scratch_side"]
+            hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])
+            hip.gemm_auto(ws["dGsum"], ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
+            hip.colsum(ws["dGsum"], gV["valrnn.lstm.bias_ih_l0"])
+            gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
+            g_emb = gV.get("valrnn.caption_embedding.weight")
+            if g_emb is not None:
+                hip.gemm_auto(ws["dGsum"], V["valrnn.lstm.weight_ih_l0"], ws["dXv"], ss, b_kmajor=True)
+                g_emb.zero_()
+                hip.scatter_add_rows(g_emb, tok_flat, 1, lv * n, ws["dXv"])
+            self._mark("side:value_input_grads_done")
+            ev_side = torch.cuda.Event()
+            ev_side.record(side)
 
-        # ---- value network: weight gradients from the chain's gate gradients
-        hip.chain_hprev(ws["saved"], tv, ws["hprev"])
-        if tv >= 16384:  # long k, small output: split-K partial slabs, summed in a fixed order
-            hip.gemm_splitk(ws["dgv"], ws["hprev"], ws["whh_slabs"], 8, a_kmajor=True, b_kmajor=True)
-            hip.sum_slabs(ws["whh_slabs"], gV["valrnn.lstm.weight_hh_l0"])
-        else:
-            hip.gemm(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], a_kmajor=True, b_kmajor=True)
-        hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])
-        hip.gemm(ws["dGsum"], ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], a_kmajor=True, b_kmajor=True)
-        hip.colsum(ws["dGsum"], gV["valrnn.lstm.bias_ih_l0"])
-        gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
-        g_emb = gV.get("valrnn.caption_embedding.weight")
-        if g_emb is not None:
-            hip.gemm(ws["dGsum"], V["valrnn.lstm.weight_ih_l0"], ws["dXv"], b_kmajor=True)
-            g_emb.zero_()
-            hip.scatter_add_rows(g_emb, tok_flat, 1, lv * n, ws["dXv"])
+        # ---- main stream: the recurrent weight gradient, sum over ~10^5 positions of dgates (x) h_prev
+        main.wait_event(ev_hprev)
+        hip.gemm_auto(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], ws["scratch_main"], a_kmajor=True,
+                      b_kmajor=True)
         self._mark("value_wgrads_done")
-        main.wait_event(ev_pol)
+        main.wait_event(ev_side)
 
     def _policy_backward(self, ws, features, n, p0, s):
         P, gP = self.P, self.gP
@@ -318,31 +348,32 @@ class A2CEngine:
         G = ws["dlogits"].view(s * n, self.vocab)
         hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G, tok_flat[p0 * n:], 1, ws["dlogp"])
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
-        hip.gemm(G, Hs, gP["linear2vocab.weight"], a_kmajor=True, b_kmajor=True)
+        ss = ws["scratch_side"]
+        hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True)
         hip.colsum(G, gP["linear2vocab.bias"])
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
-        hip.gemm(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), b_kmajor=True)
+        hip.gemm_auto(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), ss, b_kmajor=True)
         dgp = ws["dgp"]
         dc = [ws["dc0"], ws["dc1"]]
         for k in range(t_steps - 1, -1, -1):
             hip.lstm_cell_bwd(ws["gates"][k], ws["Cbuf"][k], ws["Cbuf"][k + 1], dHall[k],
                               None if k == t_steps - 1 else dc[(k + 1) & 1], dgp[k], dc[k & 1])
             if k > 0:
-                hip.gemm(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], b_kmajor=True, accumulate=True)
+                hip.gemm_auto(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], ss, b_kmajor=True, accumulate=True)
             else:
-                hip.gemm(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], b_kmajor=True)
+                hip.gemm_auto(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], ss, b_kmajor=True)
         dg_all = dgp.view(t_steps * n, 4 * H)
-        hip.gemm(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], a_kmajor=True, b_kmajor=True)
-        hip.gemm(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], a_kmajor=True,
-                 b_kmajor=True)
+        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,
+                      b_kmajor=True)
         hip.colsum(dg_all, gP["lstm.bias_ih_l0"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
-            hip.gemm(dg_all, P["lstm.weight_ih_l0"], ws["dX"], b_kmajor=True)
+            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True)
             g_emb.zero_()
             hip.scatter_add_rows(g_emb, tok_flat, 1, t_steps * n, ws["dX"])
-        hip.gemm(ws["dh0"], features, gP["cnn2linear.weight"], a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"])

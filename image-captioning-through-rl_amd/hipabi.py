@@ -21,9 +21,10 @@ SIGNATURES = {
     "icrl_last_error": (ctypes.c_char_p, []),
     "icrl_gemm_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int,
                               c_vp, c_vp, c_int, c_vp]),
+    "icrl_gemm_force_tile": (c_int, [c_int]),
     "icrl_gemm_f32_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
                                      c_int, c_vp]),
-    "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
+    "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -274,11 +275,53 @@ def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False):
     _check(rc, "icrl_gemm_f32_splitk")
 
 
-def sum_slabs(slabs, out):
+def sum_slabs(slabs, out, accumulate=False):
     splits = slabs.shape[0]
     count = slabs[0].numel()
     assert out.is_contiguous() and out.numel() == count
-    _check(load().icrl_sum_slabs(_ptr(_f32c(slabs)), count, splits, count, _ptr(out), _stream()), "icrl_sum_slabs")
+    _check(load().icrl_sum_slabs(_ptr(_f32c(slabs)), count, splits, count, _ptr(out), int(accumulate), _stream()),
+           "icrl_sum_slabs")
+
+
+def plan_gemm(m, n, k, out_contiguous=True):
+    """(tile, splits) for an [m,n,k] product, from measurements on MI355X: 64x64 tiles when the
+    k loop is short or the output is small (then split k so that ~1000 workgroups exist),
+    128x64 tiles for big outputs with a long k.  tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64."""
+    t64 = ((m + 63) // 64) * ((n + 63) // 64)
+    if k <= 1024:
+        return 3, 1
+    if t64 <= 512:
+        want = (2048 if k >= 32768 else 1024) // t64
+        splits = max(1, min(k // 512, want, 16)) if out_contiguous else 1
+        return 3, splits
+    t2 = ((m + 127) // 128) * ((n + 63) // 64)
+    splits = 2 if (t2 < 1024 and k >= 4096 and out_contiguous) else 1
+    return 2, splits
+
+
+def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None):
+    """gemm() with the tile / split-K choice of plan_gemm(); `scratch` is a flat float32 buffer for
+    the split-K partial slabs (summed in a fixed order, so results are reproducible)."""
+    m = a.shape[1] if a_kmajor else a.shape[0]
+    k = a.shape[0] if a_kmajor else a.shape[1]
+    n = b.shape[1] if b_kmajor else b.shape[0]
+    contiguous = out.is_contiguous() and bias is None
+    tile, splits = plan_gemm(m, n, k, contiguous)
+    if splits > 1 and scratch is not None and scratch.numel() >= splits * m * n:
+        slabs = scratch[:splits * m * n].view(splits, m, n)
+        load().icrl_gemm_force_tile(tile)
+        try:
+            gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
+        finally:
+            load().icrl_gemm_force_tile(0)
+        sum_slabs(slabs, out, accumulate=accumulate)
+        return out
+    load().icrl_gemm_force_tile(tile)
+    try:
+        gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias)
+    finally:
+        load().icrl_gemm_force_tile(0)
+    return out
 
 
 def chain_seg_workspace_floats(segments):

@@ -52,6 +52,10 @@ int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_ro
                   int M, int N, int K, const float* bias, const float* bias2,
                   int accumulate, icrl_stream_t stream);
 
+/* Tuning hook for measurements: 0 = choose the output tile by shape (default), 1 = 128x128,
+ * 2 = 128x64, 3 = 64x64.  Process-wide. */
+int icrl_gemm_force_tile(int tile);
+
 /* Split-K form for products with a long k and a small output (the weight gradients
  * summed over ~10^5 chain positions; the per-step products of the segment-parallel chain):
  * split z in [0, splits) writes its partial product over its k-range to
@@ -61,9 +65,9 @@ int icrl_gemm_f32_splitk(const float* A, int64_t lda, int a_kmajor, const float*
                          int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
                          int N, int K, int splits, icrl_stream_t stream);
 
-/* out[i] = sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
+/* out[i] = (accumulate ? out[i] : 0) + sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
 int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
-                   icrl_stream_t stream);
+                   int accumulate, icrl_stream_t stream);
 
 /* out[r, :] = table[idx[r*idx_stride], :]   (nn.Embedding, models.py:73, 132, 225) */
 int icrl_gather_rows(const float* table, int width, const int64_t* idx, int64_t idx_stride,

@@ -1,0 +1,26 @@
+"""Per-phase GPU timeline of one A2C minibatch at the bench workload (HIP events on the launching streams)."""
+import sys, importlib, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+import bench
+PKG = bench.PKG
+syn = importlib.import_module(PKG + ".synthetic"); models = importlib.import_module(PKG + ".models")
+optim = importlib.import_module(PKG + ".optim"); trainers = importlib.import_module(PKG + ".trainers")
+dev = torch.device("cuda", 0)
+n, vocab, caplen, fdim = 512, 10000, 20, 2048
+a2c, rew, flat, params = bench.build_networks(syn, models, optim, vocab, fdim, 0, dev)
+opt = optim.FusedAdam(flat, lr=1e-4)
+engine = trainers.build_engine(a2c, rew)
+feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, 0)
+fd = torch.from_numpy(feats).to(dev); pd = torch.from_numpy(caps[:, :1]).to(dev)
+u = torch.from_numpy(np.random.RandomState(1).random_sample((6, 19 * n))).to(dev)
+import time
+for i in range(6):
+    if i == 5: engine.trace = []
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = engine.step(fd, pd, 19, uniforms=u[i]); t1 = time.perf_counter()
+    opt.step(); res.check(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("step %d: host enqueue+seam sync %.2f ms, total %.2f ms" % (i, 1e3 * (t1 - t0), 1e3 * (t2 - t0)))
+tr = engine.trace
+t0 = tr[0][1]
+for label, ev in tr:
+    print("%-28s %8.2f ms" % (label, t0.elapsed_time(ev)))
