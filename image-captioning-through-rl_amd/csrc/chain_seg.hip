@@ -120,6 +120,31 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
             src[i] = w_hh + (int64_t)((rb >> 5) * H + u0 + (rb & 31)) * H + 4 * kq;
         }
     }
+    // The epilogue's operands (input projection row, previous c / h) do not depend on the product:
+    // fetch them now so that their HBM latency hides under the k loop.
+    constexpr int NI = (256 + NT - 1) / NT;   // epilogue items (segment row, 4 units) per thread
+    int it_state[NI];                          // 0 = none, 1 = outside the segment's range (zero state), 2 = live
+    int64_t it_pos[NI];
+    int it_s[NI], it_t[NI], it_i[NI];
+    float4 px[NI][G], pprev[NI];
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) {
+        const int item = tid + NT * ii;
+        const int j = row0 + (item >> 3), u = u0 + 4 * (item & 7);
+        it_state[ii] = 0; it_pos[ii] = 0; it_s[ii] = it_t[ii] = it_i[ii] = 0;
+        if (item >= 256 || j >= g.K) continue;
+        const int64_t seg_beg = (int64_t)j * g.Ls;
+        const int64_t pos = seg_beg - g.W + m;
+        it_pos[ii] = pos;
+        if (pos < 0 || pos >= min(g.total, seg_beg + g.Ls)) { it_state[ii] = 1; continue; }
+        it_state[ii] = 2;
+        locate(g, pos, it_s[ii], it_t[ii], it_i[ii]);
+        const float* xr = xproj + ((int64_t)it_t[ii] * g.n + it_i[ii]) * (G * H) + u;
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) px[ii][gq] = ld4(xr + gq * H);
+        pprev[ii] = ld4((G == 4 ? c_cur : h_cur) + (int64_t)j * H + u);
+    }
+
     float4 stage[PER];
     f32x16 acc;
 #pragma unroll
@@ -155,27 +180,26 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
     acc_to_lds(acc, P + q * 32 * PLD, l31, hh);
     __syncthreads();
 
-    for (int item = tid; item < 32 * 8; item += NT) {
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) {
+        if (it_state[ii] == 0) continue;
+        const int item = tid + NT * ii;
         const int rr = item >> 3, uq = 4 * (item & 7);
         const int j = row0 + rr, u = u0 + uq;
-        if (j >= g.K) continue;
         const int64_t seg_beg = (int64_t)j * g.Ls;
-        const int64_t seg_end = min(g.total, seg_beg + g.Ls);
-        const int64_t pos = seg_beg - g.W + m;
-        if (pos < 0 || pos >= seg_end) {
+        const int64_t pos = it_pos[ii];
+        if (it_state[ii] == 1) {
             st4(h_nxt + (int64_t)j * H + u, zero4());
             if (G == 4) st4(c_nxt + (int64_t)j * H + u, zero4());
             continue;
         }
-        int s, t, i;
-        locate(g, pos, s, t, i);
-        const float* xr = xproj + ((int64_t)t * g.n + i) * (G * H) + u;
+        const int s = it_s[ii], t = it_t[ii], i = it_i[ii];
         const float* pr = P + rr * PLD + uq;
         float4 h;
         if (G == 4) {
-            float4 gi = add4(ldp4(pr), ld4(xr)), gf = add4(ldp4(pr + 32 * PLD), ld4(xr + H));
-            float4 gg = add4(ldp4(pr + 64 * PLD), ld4(xr + 2 * H)), go = add4(ldp4(pr + 96 * PLD), ld4(xr + 3 * H));
-            const float4 cp = ld4(c_cur + (int64_t)j * H + u);
+            float4 gi = add4(ldp4(pr), px[ii][0]), gf = add4(ldp4(pr + 32 * PLD), px[ii][1]);
+            float4 gg = add4(ldp4(pr + 64 * PLD), px[ii][2]), go = add4(ldp4(pr + 96 * PLD), px[ii][G - 1]);
+            const float4 cp = pprev[ii];
             float4 c;
 #define CELL(k)                                                              \
     gi.k = sg(gi.k); gf.k = sg(gf.k); gg.k = th(gg.k); go.k = sg(go.k);      \
@@ -191,10 +215,10 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
             if (pos == seg_beg - 1) st4(seam_a + (int64_t)j * 2 * H + H + u, c);
             if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
         } else {
-            const float4 xr_ = ld4(xr), xz = ld4(xr + H), xn = ld4(xr + 2 * H);
+            const float4 xr_ = px[ii][0], xz = px[ii][1], xn = px[ii][2];
             const float4 hr_ = add4(ldp4(pr), ld4(b_hh + u)), hz = add4(ldp4(pr + 32 * PLD), ld4(b_hh + H + u));
             const float4 hn = add4(ldp4(pr + 64 * PLD), ld4(b_hh + 2 * H + u));
-            const float4 hp = ld4(h_cur + (int64_t)j * H + u);
+            const float4 hp = pprev[ii];
 #define CELL(k)                                              \
     {                                                        \
         const float r = sg(xr_.k + hr_.k);                   \
@@ -249,6 +273,26 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     // blocks x, x+8, ... share an XCD (round-robin dispatch): giving them the same unit tiles keeps that
     // XCD's slice of W_hh (1/8 of it) resident in its L2 across the segment-row tiles and across steps
     const int row0 = blockIdx.y * 32, u0 = blockIdx.x * 32;
+
+    // this thread's epilogue item and its operands (saved activations, carried dc, injected gradient),
+    // fetched before the k loop so that their HBM latency hides under it
+    const int rr = tid >> 3, uq = 4 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    const int64_t seg_beg = (int64_t)j * g.Ls;
+    const int64_t pos = seg_beg + g.Ls + g.W - 1 - mp;
+    const bool have_row = j < g.K;
+    const bool live = have_row && !final && pos < g.total && seg_beg < g.total;
+    float4 gi = zero4(), gf = zero4(), gg = zero4(), go = zero4(), cc = zero4(), cp = zero4(), de = zero4();
+    float4 dcv = zero4();
+    if (have_row && !final) dcv = ld4(dc + (int64_t)j * H + u);
+    if (live) {
+        int s, t, i;
+        locate(g, pos, s, t, i);
+        const float* sp = saved + pos * (6 * H) + u;
+        gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H); cc = ld4(sp + 4 * H);
+        if (pos > 0) cp = ld4(saved + (pos - 1) * (6 * H) + 4 * H + u);
+        if (t == g.p0 + s - 1) de = ld4(d_emit + ((int64_t)s * g.n + i) * H + u);
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -314,35 +358,24 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     acc_to_lds(acc, P + w * 32 * PLD, l31, hh);
     __syncthreads();
 
-    const int rr = tid >> 3, uq = 4 * (tid & 7);
-    const int j = row0 + rr, u = u0 + uq;
-    if (j >= g.K) return;
+    if (!have_row) return;
     const float* pr = P + rr * PLD + uq;
     float4 dh = add4(add4(ldp4(pr), ldp4(pr + 32 * PLD)), add4(ldp4(pr + 64 * PLD), ldp4(pr + 96 * PLD)));
     if (final) {
         st4(dh_out + (int64_t)j * H + u, dh);
         return;
     }
-    const int64_t seg_beg = (int64_t)j * g.Ls;
-    const int64_t pos = seg_beg + g.Ls + g.W - 1 - mp;
-    float4 dcv = ld4(dc + (int64_t)j * H + u);
     if (pos == seg_beg + g.Ls - 1) {  // state entering the segment's last own position
         st4(seam_a + (int64_t)j * 2 * H + u, dh);
         st4(seam_a + (int64_t)j * 2 * H + H + u, dcv);
     }
     float* dgo = dg_next + (int64_t)j * (4 * H) + u;
-    if (pos >= g.total || seg_beg >= g.total) {
+    if (!live) {
         st4(dgo, zero4()); st4(dgo + H, zero4()); st4(dgo + 2 * H, zero4()); st4(dgo + 3 * H, zero4());
         st4(dc + (int64_t)j * H + u, zero4());
         return;
     }
-    int s, t, i;
-    locate(g, pos, s, t, i);
-    if (t == g.p0 + s - 1) dh = add4(dh, ld4(d_emit + ((int64_t)s * g.n + i) * H + u));
-    const float* sp = saved + pos * (6 * H) + u;
-    const float4 gi = ld4(sp), gf = ld4(sp + H), gg = ld4(sp + 2 * H), go = ld4(sp + 3 * H), cc = ld4(sp + 4 * H);
-    float4 cp = zero4();
-    if (pos > 0) cp = ld4(saved + (pos - 1) * (6 * H) + 4 * H + u);
+    dh = add4(dh, de);
     float4 d_i, d_f, d_g, d_o, dcn;
 #define CELL(k)                                                       \
     {                                                                 \
