@@ -195,11 +195,18 @@ class A2CEngine:
         # ---- 1. policy rollout (models.py:71-84 run incrementally; trainers.py:443-458)
         Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
         hip.gemm(features, P["cnn2linear.weight"], Hb[0], bias=P["cnn2linear.bias"])
+        fused_step = self.E % 64 == 0
         for k in range(t_steps):
-            hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
-            hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"], bias2=P["lstm.bias_hh_l0"])
-            hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True)
-            hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
+            if fused_step:  # gather + both gate products + cell in one launch
+                hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k], P["lstm.weight_ih_l0"],
+                                     P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k], Cb[k],
+                                     gates[k], Cb[k + 1], Hb[k + 1], X[k])
+            else:
+                hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
+                hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"],
+                         bias2=P["lstm.bias_hh_l0"])
+                hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True)
+                hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
             if k >= p0 - 1:
                 st = k - (p0 - 1)
                 hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"])

@@ -34,6 +34,8 @@ SIGNATURES = {
     "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "icrl_policy_lstm_step": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+                                      c_vp]),
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                                    c_vp]),
     "icrl_policy_dlogits": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
@@ -350,3 +352,13 @@ def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dg
                                             n_calls, segments, warmup, _ptr(_f32c(dgates)), _ptr(_f32c(work)),
                                             _ptr(seam_err), _stream())
     _check(rc, "icrl_lstm_chain_bwd_seg")
+
+
+def policy_lstm_step(emb, tokens, w_ih, w_hh, b_ih, b_hh, h_cur, c_cur, gates_act, c_next, h_next, x_out=None):
+    """Embedding gather + both gate products + biases + LSTM cell for N rows, one launch."""
+    n = h_cur.shape[0]
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.numel() == n
+    _check(load().icrl_policy_lstm_step(_ptr(_f32c(emb)), emb.shape[1], _ptr(tokens), _ptr(_f32c(w_ih)),
+                                        _ptr(_f32c(w_hh)), _ptr(_f32c(b_ih)), _ptr(_f32c(b_hh)), _ptr(_f32c(h_cur)),
+                                        _ptr(_f32c(c_cur)), _ptr(_f32c(gates_act)), _ptr(_f32c(c_next)),
+                                        _ptr(_f32c(h_next)), _ptr(x_out), n, _stream()), "icrl_policy_lstm_step")

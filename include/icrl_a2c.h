@@ -93,6 +93,15 @@ int icrl_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float*
                        const float* dh, const float* dc, float* dgates, float* dc_prev, int N,
                        icrl_stream_t stream);
 
+/* One whole step of the policy LSTM in a single launch (models.py:73 + :80 for one position):
+ * x = emb[tokens[i]], gates = x*W_ih^T + h_cur*W_hh^T + b_ih + b_hh, then the cell.  Writes the
+ * activated gates [N,4H] (for the backward pass), c_next, h_next and, if x_out is given, the
+ * gathered embedding rows [N,wordvec_dim].  wordvec_dim must be a multiple of 64. */
+int icrl_policy_lstm_step(const float* emb, int wordvec_dim, const int64_t* tokens, const float* w_ih,
+                          const float* w_hh, const float* b_ih, const float* b_hh, const float* h_cur,
+                          const float* c_cur, float* gates_act, float* c_next, float* h_next,
+                          float* x_out, int N, icrl_stream_t stream);
+
 /* ---- batched autoregressive sampler (trainers.py:444-458, :69) ---------------
  * One workgroup per row of logits[N,V]:
  *   mode ICRL_SAMPLE: softmax in f32, float64 CDF, token = #{k : cdf[k]/cdf[V-1] <= u}

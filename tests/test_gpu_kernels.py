@@ -354,3 +354,27 @@ def test_splitk_gemm_and_slab_sum():
     hip.sum_slabs(slabs, out)
     want = a.astype(np.float64).T @ b.astype(np.float64)
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("n,e", [(45, 512), (512, 512), (7, 320)])
+def test_fused_policy_lstm_step_matches_the_unfused_kernels(n, e):
+    rs = np.random.RandomState(n + e)
+    vocab = 300
+    emb, w_ih, w_hh = rnd(rs, vocab, e), rnd(rs, 4 * H, e, scale=0.05), rnd(rs, 4 * H, H, scale=0.05)
+    b_ih, b_hh = rnd(rs, 4 * H, scale=0.1), rnd(rs, 4 * H, scale=0.1)
+    h0, c0 = rnd(rs, n, H, scale=0.5), rnd(rs, n, H)
+    tok = rs.randint(0, vocab, size=n).astype(np.int64)
+    d = {k: dev(v) for k, v in dict(emb=emb, w_ih=w_ih, w_hh=w_hh, b_ih=b_ih, b_hh=b_hh, h0=h0, c0=c0).items()}
+    tok_d = dev(tok, torch.int64)
+    gates, c1, h1 = (torch.zeros(n, 4 * H, device="cuda"), torch.zeros(n, H, device="cuda"),
+                     torch.zeros(n, H, device="cuda"))
+    x_out = torch.zeros(n, e, device="cuda")
+    hip.policy_lstm_step(d["emb"], tok_d, d["w_ih"], d["w_hh"], d["b_ih"], d["b_hh"], d["h0"], d["c0"], gates, c1, h1,
+                         x_out)
+    pre = (emb[tok].astype(np.float64) @ w_ih.T.astype(np.float64) + h0.astype(np.float64) @ w_hh.T.astype(np.float64)
+           + b_ih + b_hh)
+    act_w, c_w, h_w = ref.lstm_cell(pre, c0)
+    assert np.array_equal(x_out.cpu().numpy(), emb[tok])
+    np.testing.assert_allclose(gates.cpu().numpy(), act_w.numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(c1.cpu().numpy(), c_w.numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), h_w.numpy(), rtol=1e-5, atol=3e-6)
