@@ -78,6 +78,31 @@ __device__ __forceinline__ void tile_load(float4 (&r)[ROWS / 32], const float* b
     }
 }
 
+// Interior tiles (all rows in range, 16-byte aligned, whole k stage in range): one pointer per
+// staged float4, set up once, no bounds logic in the k loop.
+template <int ROWS, bool KM>
+__device__ __forceinline__ void tile_ptrs(const float* (&p)[ROWS / 32], const float* base, int64_t ld,
+                                          const int64_t* gather, int row0, int kbeg, int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int f = tid + 256 * i;
+        if (!KM) {
+            const int row = f >> 3, kq = f & 7;
+            const int64_t src = gather ? gather[row0 + row] : (int64_t)(row0 + row);
+            p[i] = base + src * ld + kbeg + 4 * kq;
+        } else {
+            const int k = f / (ROWS / 4), m4 = f % (ROWS / 4);
+            p[i] = base + (int64_t)(kbeg + k) * ld + row0 + 4 * m4;
+        }
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void tile_load_fast(float4 (&r)[ROWS / 32], const float* const (&p)[ROWS / 32], int64_t off) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) r[i] = *reinterpret_cast<const float4*>(p[i] + off);
+}
+
 template <int ROWS, bool KM>
 __device__ __forceinline__ void tile_store(float* lds, const float4 (&r)[ROWS / 32], int tid) {
 #pragma unroll
@@ -144,8 +169,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
     float* const Cout = g.C + (int64_t)blockIdx.y * g.slab;
-    tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg, kend, g.a_vec, tid);
-    tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg, kend, g.b_vec, tid);
+    const int nk_full = (kend - kbeg) / BK;  // stages that lie wholly inside the k range
+    const bool fast_a = g.a_vec && m0 + BM <= g.M, fast_b = g.b_vec && n0 + BN <= g.N;
+    const float* pa[BM / 32];
+    const float* pb[BN / 32];
+    if (fast_a) tile_ptrs<BM, A_KM>(pa, g.A, g.lda, g.a_rows, m0, kbeg, tid);
+    if (fast_b) tile_ptrs<BN, B_KM>(pb, g.B, g.ldb, nullptr, n0, kbeg, tid);
+    const int64_t step_a = A_KM ? (int64_t)BK * g.lda : BK, step_b = B_KM ? (int64_t)BK * g.ldb : BK;
+    if (fast_a && nk_full > 0) tile_load_fast<BM>(ra, pa, 0);
+    else tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg, kend, g.a_vec, tid);
+    if (fast_b && nk_full > 0) tile_load_fast<BN>(rb, pb, 0);
+    else tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg, kend, g.b_vec, tid);
     tile_store<BM, A_KM>(lds, ra, tid);
     tile_store<BN, B_KM>(lds + A_TILE, rb, tid);
     __syncthreads();
@@ -154,8 +188,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
         const float* lb = la + A_TILE;
         if (kt + 1 < nk) {
-            tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, tid);
-            tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, tid);
+            if (fast_a && kt + 1 < nk_full) tile_load_fast<BM>(ra, pa, (kt + 1) * step_a);
+            else tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, tid);
+            if (fast_b && kt + 1 < nk_full) tile_load_fast<BN>(rb, pb, (kt + 1) * step_b);
+            else tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, tid);
         }
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {

@@ -295,7 +295,7 @@ def plan_gemm(m, n, k, out_contiguous=True):
     if t64 <= 512:
         want = (2048 if k >= 32768 else 1024) // t64
         splits = max(1, min(k // 512, want, 16)) if out_contiguous else 1
-        return 3, splits
+        return (1 if (k >= 32768 and splits > 1) else 3), splits
     t2 = ((m + 127) // 128) * ((n + 63) // 64)
     splits = 2 if (t2 < 1024 and k >= 4096 and out_contiguous) else 1
     return 2, splits

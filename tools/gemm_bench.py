@@ -31,3 +31,5 @@ bench("dWhh_v 2048x512x97280 TN", 2048, 512, 97280, True, True, 8)
 bench("bptt 512x512x2048 NN", 512, 512, 2048, False, True, 4)
 bench("dXv 9728x512x2048 NN", 9728, 512, 2048, False, True)
 bench("cnn 512x512x2048 NT", 512, 512, 2048, False, False, 4)
+bench("cube 4096^3 NT", 4096, 4096, 4096, False, False)
+bench("cube 4096^3 TN", 4096, 4096, 4096, True, True)
