@@ -112,9 +112,10 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
         const int f = tid + NT * i;
         const int r = f / (BK / 4), kq = f % (BK / 4);
         dst[i] = (f < F4) ? r * LDT + 4 * kq : -1;
-        if (f >= F4) { src[i] = nullptr; continue; }
+        if (f >= F4) { src[i] = h_cur; continue; }
         if (r < 32) {
-            src[i] = (row0 + r < g.K) ? h_cur + (int64_t)(row0 + r) * H + 4 * kq : nullptr;
+            // rows past the last segment read a valid row instead of branching; their results are never used
+            src[i] = h_cur + (int64_t)min(row0 + r, g.K - 1) * H + 4 * kq;
         } else {
             const int rb = r - 32;
             src[i] = w_hh + (int64_t)((rb >> 5) * H + u0 + (rb & 31)) * H + 4 * kq;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
 
     if (m > 0) {  // the first step starts from a zero state: nothing to multiply
 #pragma unroll
-        for (int i = 0; i < PER; ++i) stage[i] = src[i] ? ld4(src[i]) : zero4();
+        for (int i = 0; i < PER; ++i) stage[i] = ld4(src[i]);
 #pragma unroll
         for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + dst[i], stage[i]);
         __syncthreads();
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
             const float* cur = lds + (kt & 1) * ROWS * LDT;
             if (kt + 1 < NK) {
 #pragma unroll
-                for (int i = 0; i < PER; ++i) stage[i] = src[i] ? ld4(src[i] + (kt + 1) * BK) : zero4();
+                for (int i = 0; i < PER; ++i) stage[i] = ld4(src[i] + (kt + 1) * BK);
             }
             const float* a_row = cur + l31 * LDT;
             const float* b_row = cur + (32 + q * 32 + l31) * LDT;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
         for (int i = 0; i < 8; ++i) {
             const int f = tid + 256 * i;                 // 0..2047
             const int ww = f >> 9, r = (f >> 4) & 31, kq = f & 15;
-            asrc[i] = (row0 + r < g.K) ? dg_prev + (int64_t)(row0 + r) * (4 * H) + ww * H + 4 * kq : nullptr;
+            asrc[i] = dg_prev + (int64_t)min(row0 + r, g.K - 1) * (4 * H) + ww * H + 4 * kq;
             adst[i] = ww * (A_T + B_T) + r * LDT + 4 * kq;
             const int kk = (f >> 3) & 63, uq = f & 7;
             bsrc[i] = w_hh + (int64_t)(ww * H + kk) * H + u0 + 4 * uq;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
         }
         float4 sa[8], sb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { sa[i] = asrc[i] ? ld4(asrc[i]) : zero4(); sb[i] = ld4(bsrc[i]); }
+        for (int i = 0; i < 8; ++i) { sa[i] = ld4(asrc[i]); sb[i] = ld4(bsrc[i]); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { st4(lds + adst[i], sa[i]); st4(lds + bdst[i], sb[i]); }
         __syncthreads();
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
             if (kt + 1 < NK) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    sa[i] = asrc[i] ? ld4(asrc[i] + (kt + 1) * BK) : zero4();
+                    sa[i] = ld4(asrc[i] + (kt + 1) * BK);
                     sb[i] = ld4(bsrc[i] + (int64_t)(kt + 1) * BK * H);
                 }
             }

@@ -72,15 +72,11 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_kernel(const float* __res
         dst[i] = r * LDT + 4 * kq;
         copy_x[i] = nullptr;
         if (r < 32) {
-            const int row = row0 + r;
-            if (row < N) {
-                src_x[i] = emb + tok[row] * (int64_t)E + 4 * kq;
-                src_h[i] = h_cur + (int64_t)row * H + 4 * kq;
-                if (x_out && blockIdx.x == 0) copy_x[i] = x_out + (int64_t)row * E + 4 * kq;
-            } else {
-                src_x[i] = nullptr;
-                src_h[i] = nullptr;
-            }
+            // rows past N read row N-1 instead of branching in the k loop; their results are never stored
+            const int row = min(row0 + r, N - 1);
+            src_x[i] = emb + tok[row] * (int64_t)E + 4 * kq;
+            src_h[i] = h_cur + (int64_t)row * H + 4 * kq;
+            if (x_out && blockIdx.x == 0 && row0 + r < N) copy_x[i] = x_out + (int64_t)row * E + 4 * kq;
         } else {
             const int rb = r - 32;
             const int64_t wrow = (rb >> 5) * H + u0 + (rb & 31);
@@ -103,7 +99,7 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_kernel(const float* __res
     float4 stage[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        stage[i] = src_x[i] ? ld4(src_x[i]) : zero4();
+        stage[i] = ld4(src_x[i]);
         if (copy_x[i]) st4(copy_x[i], stage[i]);
     }
 #pragma unroll
@@ -116,12 +112,12 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_kernel(const float* __res
             if (kn < nk1) {
 #pragma unroll
                 for (int i = 0; i < PER; ++i) {
-                    stage[i] = src_x[i] ? ld4(src_x[i] + kn * BK) : zero4();
+                    stage[i] = ld4(src_x[i] + kn * BK);
                     if (copy_x[i]) st4(copy_x[i] + kn * BK, stage[i]);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < PER; ++i) stage[i] = src_h[i] ? ld4(src_h[i] + (kn - nk1) * BK) : zero4();
+                for (int i = 0; i < PER; ++i) stage[i] = ld4(src_h[i] + (kn - nk1) * BK);
             }
         }
         const float* a_row = cur + l31 * LDT;
