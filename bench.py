@@ -120,12 +120,22 @@ def main():
 
     # per-kernel accounting from the HIP events recorded on each launch's own stream
     acc = {}
-    for kind, work, e0, e1 in prof:
-        a = acc.setdefault(kind, [0.0, 0.0, 0])
+    for kind, work, e0, e1, nbytes in prof:
+        a = acc.setdefault(kind, [0.0, 0.0, 0, 0.0])
         a[0] += work
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
-    gemm_flops, gemm_s, gemm_launches = acc["gemm"]
+        a[3] += nbytes
+    gemm_flops, gemm_s, gemm_launches, gemm_bytes = acc["gemm"]
+    # HBM traffic of the same launches from PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
+    # doubled as gfx950 needs), measured offline on this workload and committed under profiles/
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)["gemm_f32_kernel"]
+        traffic = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     achieved = gemm_flops / gemm_s / 1e12
     chains = {k: {"dependent_steps_per_minibatch": int(v[0] / args.steps), "us_per_step": 1e6 * v[1] / v[0],
                   "ms_per_minibatch": 1e3 * v[1] / args.steps}
@@ -158,7 +168,9 @@ def main():
                                                                      "; configs[3] data-parallel" if world > 1 else ""),
                        "global_batch": world * n, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": gemm_bytes / gemm_launches,
                          "kernel": "gemm_f32_kernel, all launches of a step (policy LSTM/vocab GEMMs fwd+bwd, "
                                    "chain input projections and weight gradients)",
                          "launches_per_step": gemm_launches // args.steps,

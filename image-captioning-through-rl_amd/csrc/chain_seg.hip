@@ -22,68 +22,30 @@
 //   backward : [32 segments] x [32 units] tile of dh = dgates . W_hh per workgroup; the four
 //              waves split the 2048 gate rows (k), their partial tiles are summed in LDS,
 //              the cell's backward runs in the epilogue and writes the next step's dgates.
-#include "icrl_common.h"
+#include "chain_seg_common.h"
 
 namespace {
 using namespace icrl;
+using namespace icrl::seg;
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr int H = kHidden;
-constexpr int BK = 64;        // k per LDS stage
-constexpr int LDT = BK + 4;   // padded row of a k-contiguous tile (ds_read_b128 conflict-free)
-constexpr int PLD = 33;       // padded row of the epilogue exchange tiles
-
-struct Geom {
-    int n, p0, n_calls;   // rows per column, columns in the first call, calls
-    int64_t total;        // positions in the chain
-    int K, Ls, W;         // segments, positions per segment, warm-up steps
-};
-
-// position -> (call s, column t, row i)
-__device__ __forceinline__ void locate(const Geom& g, int64_t pos, int& s, int& t, int& i) {
-    int64_t off = 0;
-    for (s = 0; s < g.n_calls - 1; ++s) {
-        const int64_t len = (int64_t)(g.p0 + s) * g.n;
-        if (pos < off + len) break;
-        off += len;
+// The cells, with the fused multiply-adds written out so that every kernel in this file rounds alike.
+#define LSTM_CELL1(k, gi, gf, gg, go, cp, c, h)                              \
+    gi.k = sg(gi.k); gf.k = sg(gf.k); gg.k = th(gg.k); go.k = sg(go.k);      \
+    c.k = __fmaf_rn(gf.k, cp.k, gi.k * gg.k);                                \
+    h.k = go.k * th(c.k);
+#define LSTM_CELL4(gi, gf, gg, go, cp, c, h) \
+    LSTM_CELL1(x, gi, gf, gg, go, cp, c, h) LSTM_CELL1(y, gi, gf, gg, go, cp, c, h) \
+    LSTM_CELL1(z, gi, gf, gg, go, cp, c, h) LSTM_CELL1(w, gi, gf, gg, go, cp, c, h)
+#define GRU_CELL1(k, xr, xz, xn, hr, hz, hn, hp, h)                          \
+    {                                                                        \
+        const float r_ = sg(xr.k + hr.k);                                    \
+        const float z_ = sg(xz.k + hz.k);                                    \
+        const float n_ = th(__fmaf_rn(r_, hn.k, xn.k));                      \
+        h.k = __fmaf_rn(z_, hp.k - n_, n_);                                  \
     }
-    const int64_t rem = pos - off;
-    t = (int)(rem / g.n);
-    i = (int)(rem % g.n);
-}
-
-__device__ __forceinline__ float sg(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float th(float x) { return 2.f * sg(2.f * x) - 1.f; }
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float4 ldp4(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
-
-__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
-    atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));  // order-preserving for v >= 0
-}
-
-// 8 MFMA steps of one 16-k group: lane half hh supplies k = 8*hh + s at step s for both operands
-__device__ __forceinline__ void mfma_group(f32x16& acc, const float* a_row, const float* b_row, int grp, int hh) {
-    const float4 a0 = ld4(a_row + 16 * grp + 8 * hh), a1 = ld4(a_row + 16 * grp + 8 * hh + 4);
-    const float4 b0 = ld4(b_row + 16 * grp + 8 * hh), b1 = ld4(b_row + 16 * grp + 8 * hh + 4);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
-}
-
-// accumulator register r of lane (l31, hh) is element [row = (r&3) + 8*(r>>2) + 4*hh][col = l31]
-__device__ __forceinline__ void acc_to_lds(const f32x16& acc, float* tile, int l31, int hh) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * hh) * PLD + l31] = acc[r];
-}
+#define GRU_CELL4(xr, xz, xn, hr, hz, hn, hp, h) \
+    GRU_CELL1(x, xr, xz, xn, hr, hz, hn, hp, h) GRU_CELL1(y, xr, xz, xn, hr, hz, hn, hp, h) \
+    GRU_CELL1(z, xr, xz, xn, hr, hz, hn, hp, h) GRU_CELL1(w, xr, xz, xn, hr, hz, hn, hp, h)
 
 // ------------------------------------------------------------------ forward step (LSTM: G = 4, GRU: G = 3)
 template <int G>
@@ -146,35 +108,58 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
         pprev[ii] = ld4((G == 4 ? c_cur : h_cur) + (int64_t)j * H + u);
     }
 
-    float4 stage[PER];
+    // k loop, software-pipelined so that the MFMA pipe never drains: global loads run DEPTH stages
+    // ahead in a register ring (fully unrolled, every ring slot static); operand fragments for the
+    // next 16-k group are read from LDS before the current group's MFMAs issue; the one barrier per
+    // stage sits between the last two groups, after every read of the current buffer has been issued,
+    // so the wait for the other waves hides under eight MFMAs already in flight.
+    constexpr int NK = H / BK;
+    constexpr int DEPTH = 3;
+    float4 ring[DEPTH][PER];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     if (m > 0) {  // the first step starts from a zero state: nothing to multiply
 #pragma unroll
-        for (int i = 0; i < PER; ++i) stage[i] = ld4(src[i]);
+        for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + dst[i], stage[i]);
-        __syncthreads();
-        constexpr int NK = H / BK;
-        for (int kt = 0; kt < NK; ++kt) {
-            const float* cur = lds + (kt & 1) * ROWS * LDT;
-            if (kt + 1 < NK) {
+            for (int i = 0; i < PER; ++i) ring[d][i] = ld4(src[i] + d * BK);
 #pragma unroll
-                for (int i = 0; i < PER; ++i) stage[i] = ld4(src[i] + (kt + 1) * BK);
-            }
-            const float* a_row = cur + l31 * LDT;
-            const float* b_row = cur + (32 + q * 32 + l31) * LDT;
+        for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + dst[i], ring[0][i]);
+        if (DEPTH < NK) {
 #pragma unroll
-            for (int grp = 0; grp < BK / 16; ++grp) mfma_group(acc, a_row, b_row, grp, hh);
-            if (kt + 1 < NK) {
-                float* nxt = lds + ((kt + 1) & 1) * ROWS * LDT;
-#pragma unroll
-                for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(nxt + dst[i], stage[i]);
-            }
-            __syncthreads();
+            for (int i = 0; i < PER; ++i) ring[0][i] = ld4(src[i] + DEPTH * BK);
         }
+        __syncthreads();
+        const float* a_row = lds + l31 * LDT;
+        const float* b_row = lds + (32 + q * 32 + l31) * LDT;
+        Frag f0 = load_frag(a_row, b_row, 0, hh), f1;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            constexpr int BUF = ROWS * LDT;
+            const int co = (kt & 1) * BUF, cn = ((kt + 1) & 1) * BUF;
+            f1 = load_frag(a_row + co, b_row + co, 1, hh);
+            mfma8(acc, f0);
+            if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+#pragma unroll
+                for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + cn + dst[i], ring[(kt + 1) % DEPTH][i]);
+                if (kt + 1 + DEPTH < NK) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) ring[(kt + 1) % DEPTH][i] = ld4(src[i] + (kt + 1 + DEPTH) * BK);
+                }
+            }
+            f0 = load_frag(a_row + co, b_row + co, 2, hh);
+            mfma8(acc, f1);
+            f1 = load_frag(a_row + co, b_row + co, 3, hh);
+            mfma8(acc, f0);
+            if (kt + 1 < NK) {
+                __syncthreads();
+                f0 = load_frag(a_row + cn, b_row + cn, 0, hh);
+            }
+            mfma8(acc, f1);
+        }
+        __syncthreads();  // every wave is done reading before the gate tiles overlay the stage buffers
     }
     // gate tiles meet in LDS: P[gate][segment row][unit]
     float* P = lds;
@@ -200,14 +185,8 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
         if (G == 4) {
             float4 gi = add4(ldp4(pr), px[ii][0]), gf = add4(ldp4(pr + 32 * PLD), px[ii][1]);
             float4 gg = add4(ldp4(pr + 64 * PLD), px[ii][2]), go = add4(ldp4(pr + 96 * PLD), px[ii][G - 1]);
-            const float4 cp = pprev[ii];
             float4 c;
-#define CELL(k)                                                              \
-    gi.k = sg(gi.k); gf.k = sg(gf.k); gg.k = th(gg.k); go.k = sg(go.k);      \
-    c.k = gf.k * cp.k + gi.k * gg.k;                                         \
-    h.k = go.k * th(c.k);
-            CELL(x) CELL(y) CELL(z) CELL(w)
-#undef CELL
+            LSTM_CELL4(gi, gf, gg, go, pprev[ii], c, h)
             st4(c_nxt + (int64_t)j * H + u, c);
             if (pos >= seg_beg && saved) {
                 float* sp = saved + pos * (6 * H) + u;
@@ -219,16 +198,7 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
             const float4 xr_ = px[ii][0], xz = px[ii][1], xn = px[ii][2];
             const float4 hr_ = add4(ldp4(pr), ld4(b_hh + u)), hz = add4(ldp4(pr + 32 * PLD), ld4(b_hh + H + u));
             const float4 hn = add4(ldp4(pr + 64 * PLD), ld4(b_hh + 2 * H + u));
-            const float4 hp = pprev[ii];
-#define CELL(k)                                              \
-    {                                                        \
-        const float r = sg(xr_.k + hr_.k);                   \
-        const float z = sg(xz.k + hz.k);                     \
-        const float nn = th(xn.k + r * hn.k);                \
-        h.k = (1.f - z) * nn + z * hp.k;                     \
-    }
-            CELL(x) CELL(y) CELL(z) CELL(w)
-#undef CELL
+            GRU_CELL4(xr_, xz, xn, hr_, hz, hn, pprev[ii], h)
         }
         st4(h_nxt + (int64_t)j * H + u, h);
         if (pos >= seg_beg && t == g.p0 + s - 1) st4(h_emit + ((int64_t)s * g.n + i) * H + u, h);
@@ -422,21 +392,259 @@ __global__ __launch_bounds__(256) void seam_check_bwd(const float* __restrict__ 
     }
 }
 
-int make_geom(const char* who, int N, int p0, int n_calls, int segments, int warmup, Geom& g) {
-    ICRL_REQUIRE(N > 0 && p0 > 0 && n_calls > 0, "%s: N, p0 and n_calls must be positive", who);
-    ICRL_REQUIRE(segments >= 2 && segments <= 4096 && warmup >= 1, "%s: need 2 <= segments <= 4096, warmup >= 1", who);
-    g.n = N; g.p0 = p0; g.n_calls = n_calls;
-    int64_t cols = 0;
-    for (int s = 0; s < n_calls; ++s) cols += p0 + s;
-    g.total = cols * N;
-    g.K = segments;
-    g.Ls = (int)((g.total + segments - 1) / segments);
-    g.W = warmup;
-    return ICRL_OK;
+
+// ------------------------------------------------------------------ persistent forward pair
+// Both forward chains (value LSTM, reward GRU) in ONE launch that walks every step.  Workgroups
+// [0, 16*ny) run the LSTM chain, the next 16*ny the GRU chain; a workgroup owns unit tile x of
+// segment-row tile y of its chain for all steps and keeps its cell state in registers.  At 80 KB of
+// LDS two workgroups share a CU, so one chain's waits, loads and cell arithmetic run under the other
+// chain's MFMAs.  Per step a workgroup needs the h rows of its row tile from the 16 workgroups (all
+// x) of its row group; they are handed over inside the launch, correct on any workgroup placement:
+//   producer: every h store is a 16-byte write-through (sc1) buffer store; every wave drains its
+//             stores (s_waitcnt vmcnt(0)); workgroup barrier; ONE lane stores flag[y][x] = step + 1
+//             (sc1);
+//   consumer: ONE wave polls the 16 flags of its row group with sc1 loads, workgroup barrier, then
+//             EVERY load of exchanged h bytes is a 16-byte sc1 buffer load to registers.
+// h is double-buffered by step parity: a workgroup overwrites buffer p only after it has seen all
+// 16 flags of the step in between, i.e. after every reader of p's old contents has finished.
+// W_hh is read with plain loads (nobody writes it) and stays in the XCD's L2 across steps: there is
+// no kernel boundary to invalidate it, and unit tile x runs on the XCD of block id x % 8.
+// Spins are bounded by wall clock; a timeout raises an abort word that releases every waiter, and
+// the host then poisons the seam errors so that the caller rejects the result.
+// All 2 * 16 * ny workgroups must be resident together: the host checks the CU count.
+using gu32 = __attribute__((address_space(1))) unsigned;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr int SC1 = 16;                       // buffer cache-policy bit: write-through store / L1-bypassing load
+constexpr int PDEPTH = 2;                     // stages of global loads in flight
+constexpr int PBUF = (32 + 4 * 32) * BK;      // floats per LDS stage buffer: 160 rows x 64 k, swizzled, no padding
+constexpr unsigned long long SPIN_LIMIT = 2000000ull;  // 20 ms of the 100 MHz wall clock
+
+struct ChainArgs {
+    const float* xproj; const float* w_hh; const float* b_hh;
+    float* hb;                // [2][K][H] exchanged state
+    float* saved; float* h_emit; float* seam_a; float* seam_b;
+    unsigned* flags;          // [row tiles][16]
+    Geom g;
+};
+
+__device__ __forceinline__ float4 as_f4(v4u v) { return __builtin_bit_cast(float4, v); }
+__device__ __forceinline__ v4u as_u4(float4 v) { return __builtin_bit_cast(v4u, v); }
+
+// wave 0: lanes 0..15 each poll one producer's flag, lane 16 polls the abort word
+__device__ __forceinline__ void wait_row_group(unsigned* flags16, unsigned epoch, unsigned* abort_w, int lane) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        unsigned v = epoch, ab = 0;
+        if (lane < 16) v = __hip_atomic_load((gu32*)(flags16 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (lane == 16) ab = __hip_atomic_load((gu32*)abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= epoch) || __any(ab != 0)) return;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 
-bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+// Stage buffers hold rows of 64 k-contiguous floats without padding; the 16-byte chunk c of row R
+// sits at chunk slot c ^ (R & 15), which keeps both the staging stores and the fragment reads
+// (32 lanes, 32 rows, one chunk) free of bank conflicts.
+struct FragOff { int o[4][2]; };
+__device__ __forceinline__ Frag load_frag_swz(const float* a_row, const float* b_row, const FragOff& fo, int grp) {
+    Frag f;
+    f.a0 = ld4(a_row + fo.o[grp][0]); f.a1 = ld4(a_row + fo.o[grp][1]);
+    f.b0 = ld4(b_row + fo.o[grp][0]); f.b1 = ld4(b_row + fo.o[grp][1]);
+    return f;
+}
 
+// One chain, all steps, for this workgroup's tile (bx = unit tile, by = segment-row tile).
+template <int G>
+__device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by, unsigned* abort_w, float* lds) {
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int row0 = by * 32, u0 = bx * 32;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.hb, 0, (int)(2 * (int64_t)g.K * H * sizeof(float)), 0x00020000);
+
+    // staging map: float4 (tid + 256*i) of a stage; 16 float4 per row; rows 0..31 = h, then G*32 rows of W_hh
+    const int sr = tid >> 4, kq = tid & 15;
+    const int lds_off = sr * BK + 4 * (kq ^ sr);          // every row this thread stages has R & 15 == sr
+    int a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_off[i] = (min(row0 + sr + 16 * i, g.K - 1) * H + 4 * kq) * 4;
+    // W_hh through a buffer descriptor too: one per-thread byte offset, slot and stage offsets are uniform
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w_hh), 0, (int)((int64_t)G * H * H * sizeof(float)), 0x00020000);
+    const int w_off = ((u0 + sr) * H + 4 * kq) * 4;   // slot i adds ((i>>1)*H + 16*(i&1)) * H floats
+#define W_LOAD(i, stage) \
+    as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, w_off, (((i) >> 1) * H + 16 * ((i) & 1)) * H * 4 + (stage) * BK * 4, 0))
+    FragOff fo;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) fo.o[grp][e] = 4 * ((4 * grp + 2 * hh + e) ^ (l31 & 15));
+    const float* a_row = lds + l31 * BK;
+    const float* b_row = lds + (32 + (q < G ? q : 0) * 32 + l31) * BK;
+    const bool mm = q < G;   // a GRU step has three gate tiles: the fourth wave only stages
+
+    // this thread's epilogue item: segment row j, units u..u+3; its cell state lives in registers
+    const int rr = tid >> 3, uq = 4 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    const int64_t seg_beg = (int64_t)j * g.Ls;
+    const int64_t seg_end = min(g.total, seg_beg + g.Ls);
+    float4 state = zero4();            // LSTM: c, GRU: h
+    int ps = 0, pt = 0, pi = 0;        // (call, column, row) of the current position, advanced step by step
+    bool located = false;
+    float4 bias[G == 3 ? 3 : 1];
+    if (G == 3) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) bias[gq] = ld4(a.b_hh + gq * H + u);
+    }
+
+    const int steps = g.W + g.Ls;
+    for (int m = 0; m < steps; ++m) {
+        const int cur = m & 1, nxt = cur ^ 1;
+        const int64_t pos = seg_beg - g.W + m;
+        int st = 0;   // 0 = no row, 1 = outside the segment's range (zero state), 2 = live
+        float4 px[G];
+        if (j < g.K) {
+            st = (pos < 0 || pos >= seg_end) ? 1 : 2;
+            if (st == 2) {
+                if (!located) {
+                    locate(g, pos, ps, pt, pi);
+                    located = true;
+                } else if (++pi == g.n) {
+                    pi = 0;
+                    if (++pt == g.p0 + ps) { pt = 0; ++ps; }
+                }
+                // input projection row: does not depend on the product, its latency hides under the k loop
+                const float* xr = a.xproj + ((int64_t)pt * g.n + pi) * (G * H) + u;
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) px[gq] = ld4(xr + gq * H);
+            }
+        }
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        if (m > 0) {
+            constexpr int NK = H / BK;
+            constexpr int NW = 2 * G;
+            float4 ring_w[PDEPTH][NW];
+            v4u ring_a[PDEPTH][2];
+            // W_hh does not depend on the hand-off: start its loads before waiting
+#pragma unroll
+            for (int d = 0; d < PDEPTH; ++d)
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    ring_w[d][i] = W_LOAD(i, d);
+            if (q == 0) wait_row_group(a.flags + by * 16, (unsigned)m, abort_w, lane);
+            __syncthreads();
+            const int a_base = cur * g.K * H * 4;
+#pragma unroll
+            for (int d = 0; d < PDEPTH; ++d)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    ring_a[d][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_off[i], a_base + d * BK * 4, SC1);
+
+#define STORE_STAGE(buf, slot)                                                                              \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+            st4(lds + (buf) + lds_off + 16 * i * BK, as_f4(ring_a[slot][i]));                               \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                      \
+            st4(lds + (buf) + lds_off + (32 + 16 * i) * BK, ring_w[slot][i]);                               \
+    }
+#define LOAD_STAGE(slot, stage)                                                                             \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
+            ring_a[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_off[i], a_base + (stage) * BK * 4, SC1); \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                      \
+            ring_w[slot][i] = W_LOAD(i, stage);                                                             \
+    }
+            STORE_STAGE(0, 0)
+            if (PDEPTH < NK) LOAD_STAGE(0, PDEPTH)
+            __syncthreads();
+            Frag f0, f1;
+            if (mm) f0 = load_frag_swz(a_row, b_row, fo, 0);
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                const int co = (kt & 1) * PBUF, cn = ((kt + 1) & 1) * PBUF;
+                if (mm) { f1 = load_frag_swz(a_row + co, b_row + co, fo, 1); mfma8(acc, f0); }
+                if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+                    STORE_STAGE(cn, (kt + 1) % PDEPTH)
+                    if (kt + 1 + PDEPTH < NK) LOAD_STAGE((kt + 1) % PDEPTH, kt + 1 + PDEPTH)
+                }
+                if (mm) { f0 = load_frag_swz(a_row + co, b_row + co, fo, 2); mfma8(acc, f1); }
+                if (mm) { f1 = load_frag_swz(a_row + co, b_row + co, fo, 3); mfma8(acc, f0); }
+                if (kt + 1 < NK) {
+                    __syncthreads();
+                    if (mm) f0 = load_frag_swz(a_row + cn, b_row + cn, fo, 0);
+                }
+                if (mm) mfma8(acc, f1);
+            }
+#undef STORE_STAGE
+#undef LOAD_STAGE
+            __syncthreads();  // every wave is done reading before the gate tiles overlay the stage buffers
+        }
+        float* P = lds;
+        if (mm) acc_to_lds(acc, P + q * 32 * PLD, l31, hh);
+        __syncthreads();
+
+        if (st != 0) {
+            float4 h = zero4();
+            if (st == 1) {
+                state = zero4();
+            } else {
+                const float* pr = P + rr * PLD + uq;
+                if (G == 4) {
+                    float4 gi = add4(ldp4(pr), px[0]), gf = add4(ldp4(pr + 32 * PLD), px[1]);
+                    float4 gg = add4(ldp4(pr + 64 * PLD), px[2]), go = add4(ldp4(pr + 96 * PLD), px[G - 1]);
+                    float4 c;
+                    LSTM_CELL4(gi, gf, gg, go, state, c, h)
+                    state = c;
+                    if (pos >= seg_beg && a.saved) {
+                        float* sp = a.saved + pos * (6 * H) + u;
+                        st4(sp, gi); st4(sp + H, gf); st4(sp + 2 * H, gg); st4(sp + 3 * H, go); st4(sp + 4 * H, c); st4(sp + 5 * H, h);
+                    }
+                    if (pos == seg_beg - 1) st4(a.seam_a + (int64_t)j * 2 * H + H + u, c);
+                    if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
+                } else {
+                    const float4 hr_ = add4(ldp4(pr), bias[0]), hz = add4(ldp4(pr + 32 * PLD), bias[1]);
+                    const float4 hn = add4(ldp4(pr + 64 * PLD), bias[G == 3 ? 2 : 0]);
+                    GRU_CELL4(px[0], px[1], px[2], hr_, hz, hn, state, h)
+                    state = h;
+                }
+                if (pos >= seg_beg && pt == g.p0 + ps - 1) st4(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
+                constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
+                if (pos == seg_beg - 1) st4(a.seam_a + (int64_t)j * SW + u, h);
+                if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * SW + u, h);
+            }
+            // the exchanged copy of h: write-through, 16 bytes per lane
+            __builtin_amdgcn_raw_buffer_store_b128(as_u4(h), rs, (j * H + u) * 4, nxt * g.K * H * 4, SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
+        __syncthreads();                                    // ... before ONE lane signals for all of them
+        if (tid == 0)
+            __hip_atomic_store((gu32*)(a.flags + by * 16 + bx), (unsigned)(m + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+#undef W_LOAD
+
+__global__ __launch_bounds__(256, 2) void seg_fwd_pair_persist(ChainArgs v, ChainArgs r, unsigned* abort_w, int per_chain) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PBUF];
+    const int id = blockIdx.x % per_chain;
+    if ((int)blockIdx.x < per_chain) persist_chain<4>(v, id % 16, id / 16, abort_w, lds);
+    else persist_chain<3>(r, id % 16, id / 16, abort_w, lds);
+}
+
+// after the seam checks: a launch that gave up waiting must not pass them
+__global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* seam_r) {
+    if (*abort_w != 0) { *seam_v = INFINITY; *seam_r = INFINITY; }
+}
 }  // namespace
 
 extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64_t)segments * 16 * H; }
@@ -522,6 +730,57 @@ extern "C" int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, co
                        dg[steps & 1], dgates, seam_a, dh_fin, g, steps, 1);
     hipLaunchKernelGGL(seam_check_bwd, dim3((g.K * 2 * H + 255) / 256), dim3(256), 0, st, seam_a, dh_fin, dc, g,
                        seam_err, seam_err + 1);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_chain_pair_supported(int segments) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return segments >= 2 && (H / 32) * ((segments + 31) / 32) <= cus ? 1 : 0;   // two workgroups (80 KB of LDS each) per CU
+}
+
+extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                       const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                                       int n_calls, int segments, int warmup, float* h_emit_v, float* saved_v,
+                                       float* h_emit_r, float* work_v, float* work_r, float* seam_err_v,
+                                       float* seam_err_r, icrl_stream_t stream) {
+    ChainArgs v, r;
+    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_v, n_calls, segments, warmup, v.g)) return rc;
+    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_r, n_calls, segments, warmup, r.g)) return rc;
+    ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r &&
+                 seam_err_v && seam_err_r, "icrl_chain_pair_fwd_seg: null pointer");
+    ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(xproj_r) && aligned16(w_hh_r) &&
+                 aligned16(b_hh_r) && aligned16(h_emit_v) && aligned16(saved_v) && aligned16(h_emit_r) &&
+                 aligned16(work_v) && aligned16(work_r), "icrl_chain_pair_fwd_seg: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(icrl_chain_pair_supported(segments),
+                 "icrl_chain_pair_fwd_seg: %d segments need more workgroups than the device has CUs; its workgroups "
+                 "wait for each other and must all be resident", segments);
+    hipStream_t st = icrl::as_stream(stream);
+    const int64_t kh = (int64_t)segments * H;
+    const int ny = (segments + 31) / 32;
+    // polled words (flags of both chains, abort word): a block of their own, zeroed on every call
+    unsigned* words = reinterpret_cast<unsigned*>(work_v + 12 * kh);
+    const size_t word_bytes = ((size_t)(2 * ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "icrl_chain_pair_fwd_seg: workspace too small");
+    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+    ICRL_HIP(hipMemsetAsync(work_v, 0, sizeof(float) * 2 * kh, st));
+    ICRL_HIP(hipMemsetAsync(work_r, 0, sizeof(float) * 2 * kh, st));
+    ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
+    ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
+    v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.hb = work_v; v.saved = saved_v; v.h_emit = h_emit_v;
+    v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
+    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.hb = work_r; r.saved = nullptr; r.h_emit = h_emit_r;
+    r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 16;
+    unsigned* abort_w = words + 2 * ny * 16;
+    const int per_chain = (H / 32) * ny;
+    hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, abort_w, per_chain);
+    hipLaunchKernelGGL(seam_check_fwd, dim3((v.g.K * 2 * H + 255) / 256), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
+                       2 * H, seam_err_v);
+    hipLaunchKernelGGL(seam_check_fwd, dim3((r.g.K * H + 255) / 256), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
+                       seam_err_r);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err_v, seam_err_r);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -1,0 +1,103 @@
+// Helpers shared by the segment-parallel chain kernels (per-step launches in chain_seg.hip, the
+// persistent forward pair in chain_persist.hip): chain geometry, MFMA fragment helpers, cell math.
+#pragma once
+#include "icrl_common.h"
+
+namespace icrl {
+namespace seg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int H = kHidden;
+constexpr int BK = 64;        // k per LDS stage
+constexpr int LDT = BK + 4;   // padded row of a k-contiguous tile (ds_read_b128 conflict-free)
+constexpr int PLD = 33;       // padded row of the epilogue exchange tiles
+
+struct Geom {
+    int n, p0, n_calls;   // rows per column, columns in the first call, calls
+    int64_t total;        // positions in the chain
+    int K, Ls, W;         // segments, positions per segment, warm-up steps
+};
+
+// position -> (call s, column t, row i)
+__device__ __forceinline__ void locate(const Geom& g, int64_t pos, int& s, int& t, int& i) {
+    int64_t off = 0;
+    for (s = 0; s < g.n_calls - 1; ++s) {
+        const int64_t len = (int64_t)(g.p0 + s) * g.n;
+        if (pos < off + len) break;
+        off += len;
+    }
+    const int64_t rem = pos - off;
+    t = (int)(rem / g.n);
+    i = (int)(rem % g.n);
+}
+
+__device__ __forceinline__ float sg(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float th(float x) { return 2.f * sg(2.f * x) - 1.f; }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 ldp4(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
+
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+    atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));  // order-preserving for v >= 0
+}
+
+// 8 MFMA steps of one 16-k group: lane half hh supplies k = 8*hh + s at step s for both operands
+__device__ __forceinline__ void mfma_group(f32x16& acc, const float* a_row, const float* b_row, int grp, int hh) {
+    const float4 a0 = ld4(a_row + 16 * grp + 8 * hh), a1 = ld4(a_row + 16 * grp + 8 * hh + 4);
+    const float4 b0 = ld4(b_row + 16 * grp + 8 * hh), b1 = ld4(b_row + 16 * grp + 8 * hh + 4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+}
+
+struct Frag { float4 a0, a1, b0, b1; };
+__device__ __forceinline__ Frag load_frag(const float* a_row, const float* b_row, int grp, int hh) {
+    Frag f;
+    f.a0 = ld4(a_row + 16 * grp + 8 * hh); f.a1 = ld4(a_row + 16 * grp + 8 * hh + 4);
+    f.b0 = ld4(b_row + 16 * grp + 8 * hh); f.b1 = ld4(b_row + 16 * grp + 8 * hh + 4);
+    return f;
+}
+__device__ __forceinline__ void mfma8(f32x16& acc, const Frag& f) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.x, f.b0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.y, f.b0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.z, f.b0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.w, f.b0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.x, f.b1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.y, f.b1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.z, f.b1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.w, f.b1.w, acc, 0, 0, 0);
+}
+
+// accumulator register r of lane (l31, hh) is element [row = (r&3) + 8*(r>>2) + 4*hh][col = l31]
+__device__ __forceinline__ void acc_to_lds(const f32x16& acc, float* tile, int l31, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * hh) * PLD + l31] = acc[r];
+}
+
+
+inline int make_geom(const char* who, int N, int p0, int n_calls, int segments, int warmup, Geom& g) {
+    ICRL_REQUIRE(N > 0 && p0 > 0 && n_calls > 0, "%s: N, p0 and n_calls must be positive", who);
+    ICRL_REQUIRE(segments >= 2 && segments <= 4096 && warmup >= 1, "%s: need 2 <= segments <= 4096, warmup >= 1", who);
+    g.n = N; g.p0 = p0; g.n_calls = n_calls;
+    int64_t cols = 0;
+    for (int s = 0; s < n_calls; ++s) cols += p0 + s;
+    g.total = cols * N;
+    g.K = segments;
+    g.Ls = (int)((g.total + segments - 1) / segments);
+    g.W = warmup;
+    return ICRL_OK;
+}
+
+inline bool aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+
+}  // namespace seg
+}  // namespace icrl

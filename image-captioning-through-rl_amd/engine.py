@@ -55,7 +55,7 @@ class A2CEngine:
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
 
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
-                 concurrent=True, chain_mode="auto", segments=None,
+                 concurrent=True, chain_mode="auto", segments=None, pair_kernel=True,
                  warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
@@ -63,6 +63,7 @@ class A2CEngine:
         self.P, self.V, self.R = policy_params, value_params, reward_params
         self.gP, self.gV = policy_grads or {}, value_grads or {}
         self.concurrent = concurrent
+        self.pair_kernel = pair_kernel  # both forward chains in one persistent launch when the device can hold it
         assert chain_mode in ("auto", "exact", "segmented")
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
@@ -242,29 +243,46 @@ class A2CEngine:
         tok_flat = ws["tokT"].view(-1)
         seg = plan[0] == "segmented"
 
-        # ---- 2. reward GRU chain on the side stream, value LSTM chain on the main stream
+        # ---- 2. the two forward chains: one persistent launch for both when the device can hold it,
+        # else the reward GRU chain on the side stream beside the value LSTM chain on the main stream
+        pair = seg and self.pair_kernel and hip.chain_pair_supported(plan[1])
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev_tok)
             hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["XPr"],
                      a_rows=tok_flat[:l_cols * n], bias=R["rewrnn.gru.bias_ih_l0"])
-            if seg:
+            if pair:
+                hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+                ev_xpr = torch.cuda.Event()
+                ev_xpr.record(side)
+            elif seg:
                 hip.gru_chain_fwd_seg(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                       plan[1], plan[2], ws["hr"], ws["work_r"], ws["seam"][2:4])
             else:
                 hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                   ws["hr"], ws["sync_r"], ws["status"][1:2])
-            hip.gemm(ws["hr"].view(s * n, H), R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
-            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
-            hip.cosine_reward(ws["ve"], ws["se"], s * n, n, ws["rewards"])
-            self._mark("side:reward_done")
-            ev_rew = torch.cuda.Event()
-            ev_rew.record(side)
+            if not pair:
+                self._reward_head(ws, features, n, s, side)
+                ev_rew = torch.cuda.Event()
+                ev_rew.record(side)
         hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
         hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
                  bias2=V["valrnn.lstm.bias_hh_l0"])
-        if seg:
+        if pair:
+            main.wait_event(ev_xpr)
+            hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
+                                   R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
+                                   ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
+                                   ws["seam"][0:2], ws["seam"][2:4])
+            ev_pair = torch.cuda.Event()
+            ev_pair.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_pair)
+                self._reward_head(ws, features, n, s, side, visual_done=True)
+                ev_rew = torch.cuda.Event()
+                ev_rew.record(side)
+        elif seg:
             hip.lstm_chain_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, plan[1], plan[2], ws["hv"],
                                    ws["saved"] if backward else None, ws["work_v"], ws["seam"][0:2])
         else:
@@ -284,6 +302,15 @@ class A2CEngine:
         if backward and mode != hip.GREEDY:
             self._backward(ws, features, n, p0, s, main, side, plan)
         self._mark("backward_done")
+
+    def _reward_head(self, ws, features, n, s, stream, visual_done=False):
+        """Semantic / visual embeddings and their cosine (models.py:235-240) on the current stream."""
+        R = self.R
+        hip.gemm(ws["hr"].view(s * n, H), R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
+        if not visual_done:
+            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+        hip.cosine_reward(ws["ve"], ws["se"], s * n, n, ws["rewards"])
+        self._mark("side:reward_done")
 
     # ------------------------------------------------------------------ gradients
     def _backward(self, ws, features, n, p0, s, main, side, plan):

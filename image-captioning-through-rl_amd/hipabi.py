@@ -27,6 +27,8 @@ SIGNATURES = {
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_chain_pair_supported": (c_int, [c_int]),
+    "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp] * 8),
     "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
@@ -58,13 +60,14 @@ _lib = None
 
 # When set to a list, gemm() and the chain launchers bracket each launch with HIP events
 # recorded on the stream the kernel is launched on and append (kind, work, start, end);
-# `work` is the launch's algorithmic FLOPs (GEMM) or dependent steps (chains).
+# `work` is the launch's algorithmic FLOPs (GEMM) or dependent steps (chains); a fifth field holds the
+# launch's algorithmic bytes (operands read once + result written once) for GEMM launches.
 PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, work):
-        self.kind, self.work = kind, work
+    def __init__(self, kind, work, nbytes=0.0):
+        self.kind, self.work, self.nbytes = kind, work, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -75,7 +78,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((self.kind, self.work, self.e0, self.e1))
+            PROFILE.append((self.kind, self.work, self.e0, self.e1, self.nbytes))
 
 
 def chain_positions(n, p0, n_calls):
@@ -152,7 +155,7 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     ldc = out.stride(0) if ldc is None else ldc
     if a_rows is not None:
         assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
-    with _Timed("gemm", 2.0 * m * n * k):
+    with _Timed("gemm", 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
         rc = load().icrl_gemm_f32(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor),
                                   _ptr(out), ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), _stream())
     _check(rc, "icrl_gemm_f32")
@@ -271,7 +274,7 @@ def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False):
     k = a.shape[0] if a_kmajor else a.shape[1]
     n = b.shape[1] if b_kmajor else b.shape[0]
     assert slabs.shape == (splits, m, n) and slabs.is_contiguous()
-    with _Timed("gemm", 2.0 * m * n * k):
+    with _Timed("gemm", 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
         rc = load().icrl_gemm_f32_splitk(_ptr(a), a.stride(0), int(a_kmajor), _ptr(b), b.stride(0), int(b_kmajor),
                                          _ptr(slabs), n, m * n, m, n, k, splits, _stream())
     _check(rc, "icrl_gemm_f32_splitk")
@@ -344,6 +347,24 @@ def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emi
                                            segments, warmup, _ptr(_f32c(h_emit)), _ptr(_f32c(work)), _ptr(seam_err),
                                            _stream())
     _check(rc, "icrl_gru_chain_fwd_seg")
+
+
+def chain_pair_supported(segments):
+    return bool(load().icrl_chain_pair_supported(int(segments)))
+
+
+def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, segments, warmup, h_emit_v,
+                       saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r):
+    """Value LSTM chain and reward GRU chain, every step, in one persistent launch."""
+    timed_v = _Timed("lstm_chain_fwd", chain_positions(n, p0_v, n_calls))
+    timed_r = _Timed("gru_chain_fwd", chain_positions(n, p0_r, n_calls))
+    with timed_v, timed_r:
+        rc = load().icrl_chain_pair_fwd_seg(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
+                                            _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls,
+                                            segments, warmup, _ptr(_f32c(h_emit_v)), _ptr(saved_v),
+                                            _ptr(_f32c(h_emit_r)), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
+                                            _ptr(seam_err_v), _ptr(seam_err_r), _stream())
+    _check(rc, "icrl_chain_pair_fwd_seg")
 
 
 def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err):

@@ -184,6 +184,23 @@ int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* 
                             int n_calls, int segments, int warmup, float* dgates, float* work,
                             float* seam_err, icrl_stream_t stream);
 
+/* Both forward chains of one minibatch (value LSTM: models.py:133, 140-143; reward GRU:
+ * models.py:226, 231-233) in ONE persistent launch: same results as icrl_lstm_chain_fwd_seg
+ * followed by icrl_gru_chain_fwd_seg with the same segments / warmup, bit for bit, without a
+ * kernel boundary per step.  Its workgroups (16 per 32 segments) hand the hidden state to each
+ * other inside the launch and must all be resident: icrl_chain_pair_supported(segments) says
+ * whether the current device has enough CUs, and the call fails otherwise.  p0_v / p0_r =
+ * columns of the first call of each chain (the reward chain sees one more column).  If a
+ * workgroup gives up waiting for a peer (20 ms), both seam errors are set to +inf so that
+ * the caller rejects the result like any failed seam check.  Do not run two of these
+ * launches at once on one device. */
+int icrl_chain_pair_supported(int segments);
+int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                            const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                            int n_calls, int segments, int warmup, float* h_emit_v, float* saved_v,
+                            float* h_emit_r, float* work_v, float* work_r, float* seam_err_v,
+                            float* seam_err_r, icrl_stream_t stream);
+
 /* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
 int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
                           icrl_stream_t stream);

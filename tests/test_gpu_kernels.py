@@ -330,6 +330,36 @@ def test_segmented_chains_match_the_exact_kernels(n, p0, calls, segs, warm):
     np.testing.assert_allclose(g_s.cpu().numpy(), g_x.cpu().numpy(), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("n,p0,calls,segs,warm", [(32, 1, 10, 8, 24), (16, 3, 6, 7, 12), (48, 2, 12, 96, 16), (64, 1, 19, 512, 8)])
+def test_persistent_pair_equals_the_per_step_launches(n, p0, calls, segs, warm):
+    """One launch for both forward chains, with in-launch hand-offs of the hidden state between
+    workgroups: every output must equal the per-step kernels' bit for bit, twice in a row (the second
+    call reuses the flag words and state buffers of the first)."""
+    assert hip.chain_pair_supported(segs)
+    rs = np.random.RandomState(segs + 1)
+    cols = p0 + calls
+    pos_v = n * sum(p0 + s for s in range(calls))
+    xv, wv = _chain_inputs(rs, n, cols, 4)
+    xg, wg = _chain_inputs(rs, n, cols + 1, 3)
+    xv, wv, xg, wg = dev(xv), dev(wv), dev(xg), dev(wg)
+    bg = dev(rnd(rs, 3 * H, scale=0.1))
+    work_v, err_v = _seg_ws(segs)
+    work_r, err_r = _seg_ws(segs)
+    h_s, saved_s = torch.zeros(calls, n, H, device="cuda"), torch.zeros(pos_v, 6, H, device="cuda")
+    g_s = torch.zeros(calls, n, H, device="cuda")
+    hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_s, saved_s, work_v, err_v)
+    hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm, g_s, work_r, err_r)
+    torch.cuda.synchronize()
+    ref_err = (err_v[0].item(), err_r[0].item())
+    for _ in range(2):
+        h_p, saved_p, g_p = torch.zeros_like(h_s), torch.zeros_like(saved_s), torch.zeros_like(g_s)
+        hip.chain_pair_fwd_seg(xv, wv, xg, wg, bg, n, p0, p0 + 1, calls, segs, warm, h_p, saved_p, g_p, work_v, work_r,
+                               err_v, err_r)
+        torch.cuda.synchronize()
+        assert (err_v[0].item(), err_r[0].item()) == ref_err
+        assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
+
+
 def test_seam_check_detects_a_chain_that_has_not_forgotten():
     """Forget gates pinned near 1 and a warm-up of 2 steps: the seam error must say so."""
     rs = np.random.RandomState(9)
