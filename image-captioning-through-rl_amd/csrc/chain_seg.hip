@@ -47,6 +47,22 @@ using namespace icrl::seg;
     GRU_CELL1(x, xr, xz, xn, hr, hz, hn, hp, h) GRU_CELL1(y, xr, xz, xn, hr, hz, hn, hp, h) \
     GRU_CELL1(z, xr, xz, xn, hr, hz, hn, hp, h) GRU_CELL1(w, xr, xz, xn, hr, hz, hn, hp, h)
 
+#define LSTM_BWD1(k, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)  \
+    {                                                                           \
+        const float tc = th(cc.k);                                              \
+        const float dcc = __fmaf_rn(dh.k * go.k, __fmaf_rn(-tc, tc, 1.f), dcv.k); \
+        d_i.k = dcc * gg.k * gi.k * (1.f - gi.k);                               \
+        d_f.k = dcc * cp.k * gf.k * (1.f - gf.k);                               \
+        d_g.k = dcc * gi.k * __fmaf_rn(-gg.k, gg.k, 1.f);                       \
+        d_o.k = dh.k * tc * go.k * (1.f - go.k);                                \
+        dcn.k = dcc * gf.k;                                                     \
+    }
+#define LSTM_BWD4(dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)                    \
+    LSTM_BWD1(x, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)                     \
+    LSTM_BWD1(y, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)                     \
+    LSTM_BWD1(z, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)                     \
+    LSTM_BWD1(w, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
+
 // ------------------------------------------------------------------ forward step (LSTM: G = 4, GRU: G = 3)
 template <int G>
 __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__ h_cur, const float* __restrict__ w_hh,
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
         it_pos[ii] = pos;
         if (pos < 0 || pos >= min(g.total, seg_beg + g.Ls)) { it_state[ii] = 1; continue; }
         it_state[ii] = 2;
-        locate(g, pos, it_s[ii], it_t[ii], it_i[ii]);
+        locate_fast(g, (int)pos, it_s[ii], it_t[ii], it_i[ii]);
         const float* xr = xproj + ((int64_t)it_t[ii] * g.n + it_i[ii]) * (G * H) + u;
 #pragma unroll
         for (int gq = 0; gq < G; ++gq) px[ii][gq] = ld4(xr + gq * H);
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     if (have_row && !final) dcv = ld4(dc + (int64_t)j * H + u);
     if (live) {
         int s, t, i;
-        locate(g, pos, s, t, i);
+        locate_fast(g, (int)pos, s, t, i);
         const float* sp = saved + pos * (6 * H) + u;
         gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H); cc = ld4(sp + 4 * H);
         if (pos > 0) cp = ld4(saved + (pos - 1) * (6 * H) + 4 * H + u);
@@ -348,18 +364,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     }
     dh = add4(dh, de);
     float4 d_i, d_f, d_g, d_o, dcn;
-#define CELL(k)                                                       \
-    {                                                                 \
-        const float tc = th(cc.k);                                    \
-        const float dcc = dh.k * go.k * (1.f - tc * tc) + dcv.k;      \
-        d_i.k = dcc * gg.k * gi.k * (1.f - gi.k);                     \
-        d_f.k = dcc * cp.k * gf.k * (1.f - gf.k);                     \
-        d_g.k = dcc * gi.k * (1.f - gg.k * gg.k);                     \
-        d_o.k = dh.k * tc * go.k * (1.f - go.k);                      \
-        dcn.k = dcc * gf.k;                                           \
-    }
-    CELL(x) CELL(y) CELL(z) CELL(w)
-#undef CELL
+    LSTM_BWD4(dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
     st4(dgo, d_i); st4(dgo + H, d_f); st4(dgo + 2 * H, d_g); st4(dgo + 3 * H, d_o);
     st4(dc + (int64_t)j * H + u, dcn);
     if (pos < seg_beg + g.Ls) {
@@ -494,8 +499,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
     const int64_t seg_beg = (int64_t)j * g.Ls;
     const int64_t seg_end = min(g.total, seg_beg + g.Ls);
     float4 state = zero4();            // LSTM: c, GRU: h
-    int ps = 0, pt = 0, pi = 0;        // (call, column, row) of the current position, advanced step by step
-    bool located = false;
+    int ps = 0, pt = 0, pi = 0;        // (call, column, row) of the current position
     float4 bias[G == 3 ? 3 : 1];
     if (G == 3) {
 #pragma unroll
@@ -511,13 +515,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
         if (j < g.K) {
             st = (pos < 0 || pos >= seg_end) ? 1 : 2;
             if (st == 2) {
-                if (!located) {
-                    locate(g, pos, ps, pt, pi);
-                    located = true;
-                } else if (++pi == g.n) {
-                    pi = 0;
-                    if (++pt == g.p0 + ps) { pt = 0; ++ps; }
-                }
+                locate_fast(g, (int)pos, ps, pt, pi);
                 // input projection row: does not depend on the product, its latency hides under the k loop
                 const float* xr = a.xproj + ((int64_t)pt * g.n + pi) * (G * H) + u;
 #pragma unroll
@@ -639,6 +637,193 @@ __global__ __launch_bounds__(256, 2) void seg_fwd_pair_persist(ChainArgs v, Chai
     const int id = blockIdx.x % per_chain;
     if ((int)blockIdx.x < per_chain) persist_chain<4>(v, id % 16, id / 16, abort_w, lds);
     else persist_chain<3>(r, id % 16, id / 16, abort_w, lds);
+}
+
+// ------------------------------------------------------------------ persistent LSTM backward
+// The backward chain in ONE launch, same arithmetic as seg_bwd_step step by step.  Workgroup (x, y)
+// owns dh tile [32 segment rows of tile y] x [units 32x..32x+31] for every step and carries dc in
+// registers; the dgates rows it needs each step come from the 16 workgroups of its row group through
+// the same in-launch hand-off as the forward pair (16-byte sc1 stores, drained, one flag per
+// workgroup and step; sc1 loads after the poll).  One workgroup per CU at K <= 512 segments, 70 KB of
+// LDS and at most 256 registers per lane, so that another stream's GEMM workgroups can share the CU.
+constexpr int BK2 = 32;                        // k per wave and stage (four waves: 128 gate rows per stage)
+constexpr int LDA2 = BK2 + 4;
+constexpr int TILE2 = 32 * LDA2 + BK2 * 32;    // per wave: A [32 rows][32 k] padded + B [32 k][32 units]
+constexpr int PBUF2 = 4 * TILE2;
+
+struct BwdArgs {
+    const float* w_hh; const float* saved; const float* d_emit;
+    float* dgx;               // [2][K][4H] exchanged dgates
+    float* dc; float* dgv; float* seam_a; float* dh_fin;
+    unsigned* flags;          // [row tiles][16]
+    Geom g;
+};
+
+struct FragB2 { float4 a0, a1; float b[8]; };
+__device__ __forceinline__ FragB2 load_frag2(const float* tile, int grp, int l31, int hh) {
+    FragB2 f;
+    const float* a_row = tile + l31 * LDA2 + 16 * grp + 8 * hh;
+    f.a0 = ld4(a_row); f.a1 = ld4(a_row + 4);
+    const float* bk = tile + 32 * LDA2 + (16 * grp + 8 * hh) * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f.b[s] = bk[32 * s];
+    return f;
+}
+__device__ __forceinline__ void mfma8(f32x16& acc, const FragB2& f) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.x, f.b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.y, f.b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.z, f.b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.w, f.b[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.x, f.b[4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.y, f.b[5], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.z, f.b[6], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.w, f.b[7], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* abort_w) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PBUF2];
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int bx = blockIdx.x % 16, by = blockIdx.x / 16;
+    const int row0 = by * 32, u0 = bx * 32;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.dgx, 0, (int)(2 * (int64_t)g.K * 4 * H * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w_hh), 0, (int)((int64_t)4 * H * H * sizeof(float)), 0x00020000);
+
+    // staging map: slot i of a stage belongs to wave-quarter i (gate rows i*512 ...); A: row tid/8, float4 tid%8
+    // of the 32 k; B: k row tid/8, float4 tid%8 of the 32 units
+    const int sr = tid >> 3, sq = tid & 7;
+    const int a_off = (min(row0 + sr, g.K - 1) * 4 * H + 4 * sq) * 4;   // + i*H floats + stage*BK2 floats
+    const int b_off = (sr * H + u0 + 4 * sq) * 4;                       // + (i*H + stage*BK2) * H floats
+    const int a_dst = sr * LDA2 + 4 * sq, b_dst = 32 * LDA2 + sr * 32 + 4 * sq;
+#define A_LOAD(i, stage, base) __builtin_amdgcn_raw_buffer_load_b128(rs, a_off, (base) + ((i) * H + (stage) * BK2) * 4, SC1)
+#define B_LOAD(i, stage) as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, b_off, ((i) * H + (stage) * BK2) * H * 4, 0))
+
+    // this thread's epilogue item and its carried dc
+    const int rr = tid >> 3, uq = 4 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    const int64_t seg_beg = (int64_t)j * g.Ls;
+    const bool have_row = j < g.K;
+    float4 dcv = zero4();
+    int ps = 0, pt = 0, pi = 0;
+    const float* tile = lds + w * TILE2;
+
+    const int steps = g.W + g.Ls;
+    for (int mp = 0; mp <= steps; ++mp) {
+        const bool final = mp == steps;
+        const int cur = mp & 1;   // this step writes dgx[cur]; it reads dgx[cur ^ 1]
+        const int64_t pos = seg_beg + g.Ls + g.W - 1 - mp;
+        const bool live = have_row && !final && pos < g.total && seg_beg < g.total;
+        float4 gi = zero4(), gf = zero4(), gg = zero4(), go = zero4(), cc = zero4(), cp = zero4(), de = zero4();
+        if (live) {
+            locate_fast(g, (int)pos, ps, pt, pi);
+            const float* sp = a.saved + pos * (6 * H) + u;
+            gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H); cc = ld4(sp + 4 * H);
+            if (pos > 0) cp = ld4(a.saved + (pos - 1) * (6 * H) + 4 * H + u);
+            if (pt == g.p0 + ps - 1) de = ld4(a.d_emit + ((int64_t)ps * g.n + pi) * H + u);
+        }
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        if (mp > 0) {
+            constexpr int NK = H / BK2;   // each wave walks its own 512 gate rows
+            float4 ring_b[PDEPTH][4];
+            v4u ring_a[PDEPTH][4];
+#pragma unroll
+            for (int d = 0; d < PDEPTH; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring_b[d][i] = B_LOAD(i, d);
+            if (w == 0) wait_row_group(a.flags + by * 16, (unsigned)mp, abort_w, lane);
+            __syncthreads();
+            const int a_base = (cur ^ 1) * g.K * 4 * H * 4;
+#pragma unroll
+            for (int d = 0; d < PDEPTH; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring_a[d][i] = A_LOAD(i, d, a_base);
+#define STORE_STAGE2(buf, slot)                                                                     \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+            st4(lds + (buf) + i * TILE2 + a_dst, as_f4(ring_a[slot][i]));                           \
+            st4(lds + (buf) + i * TILE2 + b_dst, ring_b[slot][i]);                                  \
+        }                                                                                           \
+    }
+#define LOAD_STAGE2(slot, stage)                                                                    \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+            ring_a[slot][i] = A_LOAD(i, stage, a_base);                                             \
+            ring_b[slot][i] = B_LOAD(i, stage);                                                     \
+        }                                                                                           \
+    }
+            STORE_STAGE2(0, 0)
+            if (PDEPTH < NK) LOAD_STAGE2(0, PDEPTH)
+            __syncthreads();
+            FragB2 f0 = load_frag2(tile, 0, l31, hh), f1;
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                const int co = (kt & 1) * PBUF2, cn = ((kt + 1) & 1) * PBUF2;
+                f1 = load_frag2(tile + co, 1, l31, hh);
+                mfma8(acc, f0);
+                if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+                    STORE_STAGE2(cn, (kt + 1) % PDEPTH)
+                    if (kt + 1 + PDEPTH < NK) LOAD_STAGE2((kt + 1) % PDEPTH, kt + 1 + PDEPTH)
+                    __syncthreads();
+                    f0 = load_frag2(tile + cn, 0, l31, hh);
+                }
+                mfma8(acc, f1);
+            }
+#undef STORE_STAGE2
+#undef LOAD_STAGE2
+            __syncthreads();  // every wave is done reading before the partial tiles overlay the stage buffers
+        }
+        float* P = lds;
+        acc_to_lds(acc, P + w * 32 * PLD, l31, hh);
+        __syncthreads();
+
+        if (have_row) {
+            const float* pr = P + rr * PLD + uq;
+            float4 dh = add4(add4(ldp4(pr), ldp4(pr + 32 * PLD)), add4(ldp4(pr + 64 * PLD), ldp4(pr + 96 * PLD)));
+            if (final) {
+                st4(a.dh_fin + (int64_t)j * H + u, dh);
+                st4(a.dc + (int64_t)j * H + u, dcv);
+            } else {
+                if (pos == seg_beg + g.Ls - 1) {  // state entering the segment's last own position
+                    st4(a.seam_a + (int64_t)j * 2 * H + u, dh);
+                    st4(a.seam_a + (int64_t)j * 2 * H + H + u, dcv);
+                }
+                float4 d_i = zero4(), d_f = zero4(), d_g = zero4(), d_o = zero4(), dcn = zero4();
+                if (live) {
+                    dh = add4(dh, de);
+                    LSTM_BWD4(dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
+                    if (pos < seg_beg + g.Ls) {
+                        float* dp = a.dgv + pos * (4 * H) + u;
+                        st4(dp, d_i); st4(dp + H, d_f); st4(dp + 2 * H, d_g); st4(dp + 3 * H, d_o);
+                    }
+                }
+                dcv = dcn;
+                // the exchanged copy of this step's dgates: write-through, 16 bytes per lane
+                const int o = (j * 4 * H + u) * 4, sb = cur * g.K * 4 * H * 4;
+                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_i), rs, o, sb, SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_f), rs, o + H * 4, sb, SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_g), rs, o + 2 * H * 4, sb, SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_o), rs, o + 3 * H * 4, sb, SC1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
+        __syncthreads();                                    // ... before ONE lane signals for all of them
+        if (tid == 0 && !final)
+            __hip_atomic_store((gu32*)(a.flags + by * 16 + bx), (unsigned)(mp + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+#undef A_LOAD
+#undef B_LOAD
+}
+
+__global__ void poison_on_abort1(const unsigned* abort_w, float* seam) {
+    if (*abort_w != 0) { seam[0] = INFINITY; seam[1] = 1.f; }
 }
 
 // after the seam checks: a launch that gave up waiting must not pass them
@@ -781,6 +966,35 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     hipLaunchKernelGGL(seam_check_fwd, dim3((r.g.K * H + 255) / 256), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
                        seam_err_r);
     hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err_v, seam_err_r);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const float* d_emit, int N,
+                                               int p0, int n_calls, int segments, int warmup, float* dgates,
+                                               float* work, float* seam_err, icrl_stream_t stream) {
+    BwdArgs a;
+    if (int rc = make_geom("icrl_lstm_chain_bwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
+    ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && seam_err, "icrl_lstm_chain_bwd_seg_persist: null pointer");
+    ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),
+                 "icrl_lstm_chain_bwd_seg_persist: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(icrl_chain_pair_supported(segments),
+                 "icrl_lstm_chain_bwd_seg_persist: %d segments need more workgroups than the device has CUs; its "
+                 "workgroups wait for each other and must all be resident", segments);
+    hipStream_t st = icrl::as_stream(stream);
+    const int64_t kh = (int64_t)segments * H;
+    const int ny = (segments + 31) / 32;
+    unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
+    const size_t word_bytes = ((size_t)(ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+    ICRL_HIP(hipMemsetAsync(seam_err, 0, 2 * sizeof(float), st));
+    a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgx = work; a.dc = work + 8 * kh; a.dgv = dgates;
+    a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
+    unsigned* abort_w = words + ny * 16;
+    hipLaunchKernelGGL(seg_bwd_persist, dim3(16 * ny), dim3(256), 0, st, a, abort_w);
+    hipLaunchKernelGGL(seam_check_bwd, dim3((a.g.K * 2 * H + 255) / 256), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
+                       a.g, seam_err, seam_err + 1);
+    hipLaunchKernelGGL(poison_on_abort1, dim3(1), dim3(1), 0, st, abort_w, seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -3,6 +3,10 @@
 #pragma once
 #include "icrl_common.h"
 
+// Per-step and persistent kernels must round alike (their results are compared bit for bit), so the
+// compiler may not choose where to fuse: only the fused multiply-adds written out below are fused.
+#pragma clang fp contract(off)
+
 namespace icrl {
 namespace seg {
 
@@ -32,8 +36,22 @@ __device__ __forceinline__ void locate(const Geom& g, int64_t pos, int& s, int& 
     i = (int)(rem % g.n);
 }
 
+// The same without a search loop (make_geom bounds the chain below 2^30 positions): the column index
+// c = pos / n, then the call s from the triangular column count C(s) = s*p0 + s(s-1)/2 <= c by a
+// float square root, corrected by at most a step either way.
+__device__ __forceinline__ void locate_fast(const Geom& g, int pos, int& s, int& t, int& i) {
+    const unsigned c = (unsigned)pos / (unsigned)g.n;
+    i = pos - (int)(c * (unsigned)g.n);
+    const float b = (float)(2 * g.p0 - 1);
+    s = (int)((__fsqrt_rn(__fmaf_rn(8.f, (float)c, b * b)) - b) * 0.5f);
+    s = min(s, g.n_calls - 1);
+    while (s * g.p0 + s * (s - 1) / 2 > (int)c) --s;
+    while (s + 1 <= g.n_calls - 1 && (s + 1) * g.p0 + (s + 1) * s / 2 <= (int)c) ++s;
+    t = (int)c - (s * g.p0 + s * (s - 1) / 2);
+}
+
 __device__ __forceinline__ float sg(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float th(float x) { return 2.f * sg(2.f * x) - 1.f; }
+__device__ __forceinline__ float th(float x) { return __fmaf_rn(2.f, sg(2.f * x), -1.f); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -90,6 +108,7 @@ inline int make_geom(const char* who, int N, int p0, int n_calls, int segments, 
     int64_t cols = 0;
     for (int s = 0; s < n_calls; ++s) cols += p0 + s;
     g.total = cols * N;
+    ICRL_REQUIRE(g.total < (int64_t)1 << 30, "%s: chains of 2^30 or more positions are not supported", who);
     g.K = segments;
     g.Ls = (int)((g.total + segments - 1) / segments);
     g.W = warmup;

@@ -55,7 +55,7 @@ class A2CEngine:
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
 
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
-                 concurrent=True, chain_mode="auto", segments=None, pair_kernel=True,
+                 concurrent=True, chain_mode="auto", segments=None, persistent=True,
                  warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
@@ -63,7 +63,7 @@ class A2CEngine:
         self.P, self.V, self.R = policy_params, value_params, reward_params
         self.gP, self.gV = policy_grads or {}, value_grads or {}
         self.concurrent = concurrent
-        self.pair_kernel = pair_kernel  # both forward chains in one persistent launch when the device can hold it
+        self.persistent = persistent  # persistent chain kernels (one launch for all steps) when the device can hold them
         assert chain_mode in ("auto", "exact", "segmented")
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
@@ -245,7 +245,7 @@ class A2CEngine:
 
         # ---- 2. the two forward chains: one persistent launch for both when the device can hold it,
         # else the reward GRU chain on the side stream beside the value LSTM chain on the main stream
-        pair = seg and self.pair_kernel and hip.chain_pair_supported(plan[1])
+        pair = seg and self.persistent and hip.chain_pair_supported(plan[1])
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
@@ -335,7 +335,8 @@ class A2CEngine:
         hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
         if plan[0] == "segmented":
             hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, plan[1], plan[2],
-                                   ws["dgv"], ws["work_v"], ws["seam"][4:6])
+                                   ws["dgv"], ws["work_v"], ws["seam"][4:6],
+                                   persistent=self.persistent and hip.chain_pair_supported(plan[1]))
         else:
             hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
                                ws["sync_v"], ws["status"][2:3])

@@ -28,6 +28,7 @@ SIGNATURES = {
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_supported": (c_int, [c_int]),
+    "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp] * 8),
     "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -367,9 +368,10 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
     _check(rc, "icrl_chain_pair_fwd_seg")
 
 
-def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err):
+def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False):
+    fn = load().icrl_lstm_chain_bwd_seg_persist if persistent else load().icrl_lstm_chain_bwd_seg
     with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
-        rc = load().icrl_lstm_chain_bwd_seg(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
+        rc = fn(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
                                             n_calls, segments, warmup, _ptr(_f32c(dgates)), _ptr(_f32c(work)),
                                             _ptr(seam_err), _stream())
     _check(rc, "icrl_lstm_chain_bwd_seg")

@@ -201,6 +201,13 @@ int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const flo
                             float* h_emit_r, float* work_v, float* work_r, float* seam_err_v,
                             float* seam_err_r, icrl_stream_t stream);
 
+/* icrl_lstm_chain_bwd_seg (the BPTT of models.py:140-143's recurrence) as ONE persistent
+ * launch: same arguments, same results bit for bit, no kernel boundary per step.  Needs
+ * icrl_chain_pair_supported(segments); a hand-off time-out sets seam_err[0] = +inf. */
+int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const float* d_emit, int N,
+                                    int p0, int n_calls, int segments, int warmup, float* dgates,
+                                    float* work, float* seam_err, icrl_stream_t stream);
+
 /* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
 int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
                           icrl_stream_t stream);

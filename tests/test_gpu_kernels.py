@@ -331,7 +331,7 @@ def test_segmented_chains_match_the_exact_kernels(n, p0, calls, segs, warm):
 
 
 @pytest.mark.parametrize("n,p0,calls,segs,warm", [(32, 1, 10, 8, 24), (16, 3, 6, 7, 12), (48, 2, 12, 96, 16), (64, 1, 19, 512, 8)])
-def test_persistent_pair_equals_the_per_step_launches(n, p0, calls, segs, warm):
+def test_persistent_chains_equal_the_per_step_launches(n, p0, calls, segs, warm):
     """One launch for both forward chains, with in-launch hand-offs of the hidden state between
     workgroups: every output must equal the per-step kernels' bit for bit, twice in a row (the second
     call reuses the flag words and state buffers of the first)."""
@@ -358,6 +358,17 @@ def test_persistent_pair_equals_the_per_step_launches(n, p0, calls, segs, warm):
         torch.cuda.synchronize()
         assert (err_v[0].item(), err_r[0].item()) == ref_err
         assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
+    # the backward chain: persistent launch against the per-step launches
+    d_emit = dev(rnd(rs, calls, n, H, scale=0.01))
+    dg_s = torch.zeros(pos_v, 4 * H, device="cuda")
+    err_b, err_p = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    hip.lstm_chain_bwd_seg(wv, saved_s, d_emit, n, p0, calls, segs, warm, dg_s, work_v, err_b)
+    for _ in range(2):
+        dg_p = torch.full_like(dg_s, float("nan"))
+        hip.lstm_chain_bwd_seg(wv, saved_s, d_emit, n, p0, calls, segs, warm, dg_p, work_v, err_p, persistent=True)
+        torch.cuda.synchronize()
+        assert torch.equal(err_p, err_b)
+        assert torch.equal(dg_p, dg_s)
 
 
 def test_seam_check_detects_a_chain_that_has_not_forgotten():

@@ -100,4 +100,32 @@ if hip.chain_pair_supported(K):
     bad = (d > 0).nonzero()
     print("hv mismatches", bad.shape[0], "max", float(d.max()), "first", bad[:5].tolist())
 timeit("lstm bwd alone", bwd_v, steps_v + 1)
+if hip.chain_pair_supported(K):
+    dgv2 = torch.empty_like(dgv)
+    seam3 = torch.zeros(2, device=dev)
+    timeit("lstm bwd persistent", lambda: hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv2, work_v, seam3,
+                                                                 persistent=True), steps_v + 1)
+    bwd_v(); torch.cuda.synchronize()
+    print("bwd persistent == per-step:", torch.equal(dgv, dgv2), seam3.tolist(), float((dgv - dgv2).abs().max()))
 print("seam", seam.tolist())
+if hip.chain_pair_supported(K):
+    dgv3 = torch.empty_like(dgv)
+    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv3, work_v, seam3, persistent=True)
+    torch.cuda.synchronize()
+    print("persistent run-to-run equal:", torch.equal(dgv2, dgv3))
+    dgv4 = torch.empty_like(dgv)
+    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv4, work_v, seam3)
+    torch.cuda.synchronize()
+    print("per-step run-to-run equal:", torch.equal(dgv, dgv4))
+    d = (dgv - dgv2).abs()
+    bad = (d > 0).nonzero()
+    print("mismatches", bad.shape[0], "of", d.numel(), "first", bad[:4].tolist(), "last", bad[-4:].tolist())
+    rel = d / dgv.abs().clamp_min(1e-30)
+    print("max rel", float(rel.max()), "median rel of mismatches", float(rel[d > 0].median()))
+    Ls = (tv + K - 1) // K
+    big = (d > 1e-3 * dgv.abs().max()).any(dim=1).nonzero().flatten()
+    segs_bad = torch.unique(big // Ls)
+    print("positions badly off:", big.numel(), "segments:", segs_bad.numel(), segs_bad[:40].tolist())
+    if big.numel():
+        offs = (big % Ls)
+        print("offset within segment: min", int(offs.min()), "max", int(offs.max()))
