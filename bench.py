@@ -148,10 +148,11 @@ def main():
     # MFMA work the segment-parallel chain kernels executed (warm-up steps included): per launch one
     # [segments, 512] x [512, G*512] product; the chain events above time those launches
     seg_flops = 0.0
-    plan = res.chain_plan
-    if plan[0] == "segmented":
-        _, segs, warm = plan
-        for kind, gates, p0 in (("lstm_chain_fwd", 4, 1), ("gru_chain_fwd", 3, 2), ("lstm_chain_bwd", 4, 1)):
+    plan_fwd, plan_bwd = res.chain_plan
+    for kind, gates, p0, plan in (("lstm_chain_fwd", 4, 1, plan_fwd), ("gru_chain_fwd", 3, 2, plan_fwd),
+                                  ("lstm_chain_bwd", 4, 1, plan_bwd)):
+        if plan[0] == "segmented":
+            _, segs, warm = plan
             positions = hip.chain_positions(n, p0, steps_per_rollout)
             launches = warm + (positions + segs - 1) // segs
             seg_flops += launches * 2.0 * segs * 512 * gates * 512
@@ -187,7 +188,7 @@ def main():
                 "policy_flops_per_image_fwd_bwd": policy_flops_per_image,
                 "achieved_tflops": policy_flops_per_image * value / world / 1e12,
                 "frac_of_f32_mfma_peak": policy_flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS},
-            "chain_plan": list(res.chain_plan), "seam_check": engine.last_seam,
+            "chain_plan": {"forward": list(plan_fwd), "backward": list(plan_bwd)}, "seam_check": engine.last_seam,
             "seam_fallbacks_in_run": engine.fallbacks, "last_loss": float(res.scalars[0]),
         }
         if world == 1 and not args.no_cpu_baseline:

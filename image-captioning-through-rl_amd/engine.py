@@ -68,7 +68,10 @@ class A2CEngine:
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
-        self._first_plan = 0  # plans that failed once are not tried first again (parameters drift slowly)
+        # where each direction starts in the warm-up ladder: a length that failed once, or came close to
+        # failing, is not tried first again (the parameters drift slowly from step to step)
+        self._first_fwd = 0
+        self._first_bwd = 0
         self.last_seam = None
         self._ws = {}
         self._side = None
@@ -139,17 +142,17 @@ class A2CEngine:
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
 
-    def _next_plan(self, plans, attempt, seam, with_bwd):
+    @staticmethod
+    def _next_plan(plans, attempt, checks):
         """After a rejected attempt: the seam error shrinks geometrically with the warm-up length
         (from an O(1) initial mismatch), so estimate the length that reaches a tenth of the
-        tolerance and jump to the first plan at least that long."""
+        tolerance and jump to the first plan at least that long.  checks: [(error, tolerance)]."""
         import math
         w = plans[attempt][2]
         need = w + 1
-        checks = [(seam[0], self.SEAM_TOL_FWD), (seam[2], self.SEAM_TOL_FWD)]
-        if with_bwd and seam[5] > 0:
-            checks.append((seam[4] / seam[5], self.SEAM_TOL_BWD))
         for err, tol in checks:
+            if err > tol and tol <= 0:
+                return len(plans) - 1
             if err > tol and 0 < err < 0.5:
                 need = max(need, int(math.ceil(w * math.log(tol / 10.0) / math.log(err))))
             elif err >= 0.5 or err != err:
@@ -218,26 +221,44 @@ class A2CEngine:
         self._mark("rollout_done")
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
-        idx = min(self._first_plan, len(plans) - 1)
+        last = len(plans) - 1
+        fi, bi = min(self._first_fwd, last), min(self._first_bwd, last)
+        with_bwd = backward and mode != hip.GREEDY
+        redo_forward = True
         while True:
-            plan = plans[idx]
-            self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, plan)
-            if plan[0] == "exact":
+            pf, pb = plans[fi], plans[bi]
+            if redo_forward:
+                self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, pf, pb)
+            else:  # only the value chain's BPTT was rejected: everything before it stands
+                self._value_chain_backward(ws, n, p0, s, main, side, pb, None)
+                self._mark("backward_done")
+            seg_f, seg_b = pf[0] == "segmented", with_bwd and pb[0] == "segmented"
+            if not (seg_f or seg_b):
                 break
             seam = ws["seam"].tolist()  # host sync; the caller synchronises per step anyway
             self.last_seam = seam
-            with_bwd = backward and mode != hip.GREEDY
-            ok = (seam[0] <= self.SEAM_TOL_FWD and seam[2] <= self.SEAM_TOL_FWD
-                  and (not with_bwd or seam[4] <= self.SEAM_TOL_BWD * seam[5] + 1e-30))
-            if ok:
+            fwd_checks = [(seam[0], self.SEAM_TOL_FWD), (seam[2], self.SEAM_TOL_FWD)] if seg_f else []
+            bwd_checks = [(seam[4] / seam[5] if seam[5] > 0 else 0.0, self.SEAM_TOL_BWD)] if seg_b else []
+            ok_f = all(e <= t for e, t in fwd_checks)
+            ok_b = all(e <= t for e, t in bwd_checks)
+            if ok_f and ok_b:
+                # a length that only just passed is not tried first on the next minibatch
+                if seg_f and fi == self._first_fwd and any(e > 0.3 * t for e, t in fwd_checks):
+                    self._first_fwd = min(fi + 1, last)
+                if seg_b and bi == self._first_bwd and any(e > 0.3 * t for e, t in bwd_checks):
+                    self._first_bwd = min(bi + 1, last)
                 break
             self.fallbacks += 1
-            idx = self._first_plan = self._next_plan(plans, idx, seam, with_bwd)
+            redo_forward = not ok_f
+            if not ok_f:
+                fi = self._first_fwd = self._next_plan(plans, fi, fwd_checks)
+            if not ok_b:
+                bi = self._first_bwd = self._next_plan(plans, bi, bwd_checks)
         return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                              ws["rewards"].view(s, n).t().contiguous(), ws["scalars"], ws["entropy"], ws["status"],
-                             plan)
+                             (pf, pb))
 
-    def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan):
+    def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan, plan_bwd):
         P, V, R = self.P, self.V, self.R
         t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
         tok_flat = ws["tokT"].view(-1)
@@ -300,7 +321,7 @@ class A2CEngine:
                      ws["dvalue"] if backward else None, ws["dlogp"] if backward else None)
         self._mark("loss_done")
         if backward and mode != hip.GREEDY:
-            self._backward(ws, features, n, p0, s, main, side, plan)
+            self._backward(ws, features, n, p0, s, main, side, plan_bwd)
         self._mark("backward_done")
 
     def _reward_head(self, ws, features, n, s, stream, visual_done=False):
@@ -333,6 +354,15 @@ class A2CEngine:
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
         hip.colsum(dY, gV["linear1.bias"])
         hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
+        self._value_chain_backward(ws, n, p0, s, main, side, plan, ev_loss, features)
+
+    def _value_chain_backward(self, ws, n, p0, s, main, side, plan, ev_loss, features=None):
+        """The value chain's BPTT and everything that consumes it.  With ev_loss the side stream also
+        runs the policy network's BPTT beside the chain (first attempt of a step); without, only the
+        chain's part is redone (after a rejected seam check)."""
+        V, gV = self.V, self.gV
+        lv, tv = p0 + s - 1, ws["tv"]
+        tok_flat = ws["tokT"].view(-1)
         if plan[0] == "segmented":
             hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, plan[1], plan[2],
                                    ws["dgv"], ws["work_v"], ws["seam"][4:6],
@@ -347,13 +377,14 @@ class A2CEngine:
         # ---- side stream: the shifted h stream (needs only forward results), the policy network's BPTT
         # beside the value chain, then the value network's input-side gradients once the chain is done
         with torch.cuda.stream(side):
-            side.wait_event(ev_loss)
-            hip.chain_hprev(ws["saved"], tv, ws["hprev"])
-            ev_hprev = torch.cuda.Event()
-            ev_hprev.record(side)
-            self._mark("side:policy_bwd_start")
-            self._policy_backward(ws, features, n, p0, s)
-            self._mark("side:policy_bwd_done")
+            if ev_loss is not None:
+                side.wait_event(ev_loss)
+                hip.chain_hprev(ws["saved"], tv, ws["hprev"])
+                ev_hprev = torch.cuda.Event()
+                ev_hprev.record(side)
+                self._mark("side:policy_bwd_start")
+                self._policy_backward(ws, features, n, p0, s)
+                self._mark("side:policy_bwd_done")
             side.wait_event(ev_chain)
             ss = ws["scratch_side"]
             hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])
@@ -370,7 +401,8 @@ class A2CEngine:
             ev_side.record(side)
 
         # ---- main stream: the recurrent weight gradient, sum over ~10^5 positions of dgates (x) h_prev
-        main.wait_event(ev_hprev)
+        if ev_loss is not None:
+            main.wait_event(ev_hprev)
         hip.gemm_auto(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], ws["scratch_main"], a_kmajor=True,
                       b_kmajor=True)
         self._mark("value_wgrads_done")

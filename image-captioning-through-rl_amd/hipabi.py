@@ -357,9 +357,7 @@ def chain_pair_supported(segments):
 def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, segments, warmup, h_emit_v,
                        saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r):
     """Value LSTM chain and reward GRU chain, every step, in one persistent launch."""
-    timed_v = _Timed("lstm_chain_fwd", chain_positions(n, p0_v, n_calls))
-    timed_r = _Timed("gru_chain_fwd", chain_positions(n, p0_r, n_calls))
-    with timed_v, timed_r:
+    with _Timed("chain_pair_fwd", chain_positions(n, p0_v, n_calls) + chain_positions(n, p0_r, n_calls)):
         rc = load().icrl_chain_pair_fwd_seg(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
                                             _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls,
                                             segments, warmup, _ptr(_f32c(h_emit_v)), _ptr(saved_v),

@@ -217,8 +217,10 @@ def _grads(a2c):
     return {k: p.grad.clone() for k, p in a2c.named_parameters()}
 
 
-def _step_with(a2c, rew, feats, caps, steps, u, **opts):
+def _step_with(a2c, rew, feats, caps, steps, u, tol_bwd=None, **opts):
     engine = trainers.build_engine(a2c, rew, **opts)
+    if tol_bwd is not None:
+        engine.SEAM_TOL_BWD = tol_bwd
     res = engine.step(torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :1]).cuda(), steps,
                       uniforms=torch.from_numpy(u).cuda()).check()
     torch.cuda.synchronize()
@@ -233,13 +235,30 @@ def test_segmented_chains_give_the_exact_step():
     feats, caps = synthetic.make_minibatch(64, 500, 14, 2048, 3)
     u = synthetic.make_uniforms(3, 13 * 64)
     _, exact, g_exact = _step_with(a2c, rew, feats, caps, 13, u, chain_mode="exact")
-    assert exact.chain_plan == ("exact",)
+    assert exact.chain_plan == (("exact",), ("exact",))
     eng, seg, g_seg = _step_with(a2c, rew, feats, caps, 13, u, chain_mode="segmented", segments=24, warmups=(96,))
-    assert seg.chain_plan == ("segmented", 24, 96) and eng.fallbacks == 0
+    assert seg.chain_plan == (("segmented", 24, 96), ("segmented", 24, 96)) and eng.fallbacks == 0
     assert torch.equal(seg.tokens, exact.tokens)
     np.testing.assert_allclose(seg.values.cpu().numpy(), exact.values.cpu().numpy(), rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(seg.rewards.cpu().numpy(), exact.rewards.cpu().numpy(), rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(seg.scalars.cpu().numpy()[:5], exact.scalars.cpu().numpy()[:5], rtol=1e-5, atol=1e-7)
+    for k in g_exact:
+        scale = g_exact[k].pow(2).mean().sqrt().item() + 1e-12
+        assert (g_seg[k] - g_exact[k]).abs().max().item() <= 1e-3 * scale + 1e-9, k
+
+
+def test_rejected_backward_seam_redoes_only_the_value_chain():
+    """A backward tolerance nothing can meet: the forward chains stand, the value chain's BPTT is redone
+    with the exact kernel, and every gradient still matches the all-exact step."""
+    cfg = dict(n=64, vocab=500, caplen=14, fdim=2048, seed=5, level=None)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(64, 500, 14, 2048, 5)
+    u = synthetic.make_uniforms(5, 13 * 64)
+    _, exact, g_exact = _step_with(a2c, rew, feats, caps, 13, u, chain_mode="exact")
+    eng, seg, g_seg = _step_with(a2c, rew, feats, caps, 13, u, tol_bwd=0.0, chain_mode="segmented", segments=24,
+                                 warmups=(96,))
+    assert seg.chain_plan == (("segmented", 24, 96), ("exact",)) and eng.fallbacks == 1
+    assert torch.equal(seg.tokens, exact.tokens)
     for k in g_exact:
         scale = g_exact[k].pow(2).mean().sqrt().item() + 1e-12
         assert (g_seg[k] - g_exact[k]).abs().max().item() <= 1e-3 * scale + 1e-9, k
@@ -256,7 +275,7 @@ def test_seam_check_rejects_and_falls_back_to_the_exact_kernels():
     u = synthetic.make_uniforms(4, 9 * 32)
     _, exact, g_exact = _step_with(a2c, rew, feats, caps, 9, u, chain_mode="exact")
     eng, seg, g_seg = _step_with(a2c, rew, feats, caps, 9, u, chain_mode="segmented", segments=8, warmups=(2,))
-    assert eng.fallbacks == 1 and seg.chain_plan == ("exact",)
+    assert eng.fallbacks == 1 and seg.chain_plan == (("exact",), ("exact",))
     assert torch.equal(seg.values, exact.values)
     for k in g_exact:
         scale = g_exact[k].pow(2).mean().sqrt().item() + 1e-12
