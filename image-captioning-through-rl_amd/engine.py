@@ -9,8 +9,7 @@ reference's Python loop; it computes the same numbers in a different order:
      prefix and projects every position each step, models.py:71-84, 286);
   2. once all tokens exist, the value network's batch-1 LSTM recurrence and the reward
      network's batch-1 GRU recurrence (models.py:133, 226 fed (N,1,E) without
-     batch_first) each run as ONE persistent kernel over every step's prefix, on two
-     HIP streams at once;
+     batch_first) run over every step's prefix, both chains at once;
   3. loss (trainers.py:471-475), then the policy BPTT on one stream beside the value
      chain's BPTT on the other.
 
@@ -18,9 +17,12 @@ The two recurrences can be evaluated in two ways (``chain_mode``):
   * "exact": the persistent kernels of chain.hip walk the ~10^5 dependent steps one by one;
   * "segmented": chain_seg.hip cuts the chain into segments that run side by side after a
     warm-up, and reports how far each segment's warmed-up state was from the true state at
-    its seam.  The step is accepted only if every seam agrees to rounding level; otherwise
+    its seam.  A result is accepted only if every seam agrees to rounding level; otherwise
     it is redone with a longer warm-up and finally with the exact kernels, so the result
-    never depends on the recurrence forgetting fast enough;
+    never depends on the recurrence forgetting fast enough.  Forward and backward keep their
+    own warm-up length; a rejected backward seam redoes only the value chain's BPTT.  With
+    ``persistent`` (default) and at most 512 segments all steps of the two forward chains
+    run in one launch, and all steps of the backward chain in another;
   * "auto" (default): segmented for chains of at least 8192 positions, else exact.
 
 All device memory is PyTorch-owned and cached per problem shape; nothing here touches
