@@ -681,7 +681,11 @@ __device__ __forceinline__ void mfma8(f32x16& acc, const FragB2& f) {
 }
 
 __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* abort_w) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * PBUF2];
+    // 84 KB although the stages need 70: two of these workgroups must never share a CU (they would
+    // halve the chain's speed for the whole launch), while a GEMM workgroup of another stream still fits
+    constexpr int LDS_FLOATS = 21 * 1024;
+    static_assert(LDS_FLOATS >= 2 * PBUF2, "stage buffers");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;

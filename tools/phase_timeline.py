@@ -19,7 +19,7 @@ for i in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = engine.step(fd, pd, 19, uniforms=u[i]); t1 = time.perf_counter()
     opt.step(); res.check(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print("step %d: host enqueue+seam sync %.2f ms, total %.2f ms" % (i, 1e3 * (t1 - t0), 1e3 * (t2 - t0)))
+    print("step %d: host enqueue+seam sync %.2f ms, total %.2f ms, plan %s, fallbacks %d" % (i, 1e3 * (t1 - t0), 1e3 * (t2 - t0), res.chain_plan, engine.fallbacks))
 tr = engine.trace
 t0 = tr[0][1]
 for label, ev in tr:
