@@ -69,15 +69,37 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         return;
     }
 
-    // pass 1: row -> LDS, maximum
+    // pass 1: row -> LDS, maximum (16-byte loads when the row allows, all of a thread's loads in flight)
     float m = -INFINITY;
-    for (int k = tid; k < V; k += 256) {
-        const float v = src[k];
-        row[k] = v;
-        m = fmaxf(m, v);
+    const bool vec = (V % 4 == 0) && (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(logits) % 16 == 0) &&
+                     (!probs || reinterpret_cast<uintptr_t>(probs) % 16 == 0);
+    if (vec) {
+        const int v4 = V / 4;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4* row4 = reinterpret_cast<float4*>(row);
+        for (int k0 = 0; k0 < v4; k0 += 256 * 4) {
+            float4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + tid + 256 * j;
+                t[j] = (k < v4) ? src4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + tid + 256 * j;
+                if (k < v4) row4[k] = t[j];
+                m = fmaxf(fmaxf(m, fmaxf(t[j].x, t[j].y)), fmaxf(t[j].z, t[j].w));
+            }
+        }
+    } else {
+        for (int k = tid; k < V; k += 256) {
+            const float v = src[k];
+            row[k] = v;
+            m = fmaxf(m, v);
+        }
     }
     m = block_max(m, redf);
-    // pass 2: exponentials, their float32 sum
+    // pass 2: exponentials, their float32 sum (element order of the sum: strided by 256, as below)
     float s = 0.f;
     for (int k = tid; k < V; k += 256) {
         const float e = expf(row[k] - m);
@@ -87,11 +109,29 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     s = block_sum(s, redf);
     // pass 3: probabilities (float32 division, as torch's softmax does), optional outputs
     float ent = 0.f;
-    for (int k = tid; k < V; k += 256) {
-        const float p = row[k] / s;
-        row[k] = p;
-        if (probs) probs[(int64_t)r * V + k] = p;
-        if (entropy && p > 0.f) ent -= p * logf(p);
+    if (vec) {
+        const int v4 = V / 4;
+        float4* row4 = reinterpret_cast<float4*>(row);
+        float4* out4 = probs ? reinterpret_cast<float4*>(probs + (int64_t)r * V) : nullptr;
+        for (int k = tid; k < v4; k += 256) {
+            float4 p = row4[k];
+            p.x /= s; p.y /= s; p.z /= s; p.w /= s;
+            row4[k] = p;
+            if (out4) out4[k] = p;
+            if (entropy) {
+                if (p.x > 0.f) ent -= p.x * logf(p.x);
+                if (p.y > 0.f) ent -= p.y * logf(p.y);
+                if (p.z > 0.f) ent -= p.z * logf(p.z);
+                if (p.w > 0.f) ent -= p.w * logf(p.w);
+            }
+        }
+    } else {
+        for (int k = tid; k < V; k += 256) {
+            const float p = row[k] / s;
+            row[k] = p;
+            if (probs) probs[(int64_t)r * V + k] = p;
+            if (entropy && p > 0.f) ent -= p * logf(p);
+        }
     }
     if (entropy) {
         ent = block_sum(ent, redf);
@@ -121,10 +161,16 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         }
         double running = wave_off + inc - local;  // exclusive prefix of this chunk
         const double u = uniforms[r];
+        // count CDF entries running/total <= u.  The float64 division is only needed when the entry is
+        // within rounding distance of u: elsewhere the comparison against u*total gives the same answer
+        // (a quotient's relative error is 2^-53, the guard band is 2^-40).
+        const double ut = u * total, band = total * 0x1p-40;
         int cnt = 0;
         for (int k = k0; k < k1; ++k) {
             running += (double)row[k];
-            cnt += (running / total <= u) ? 1 : 0;
+            const double d = running - ut;
+            if (fabs(d) > band) cnt += (d < 0.) ? 1 : 0;
+            else cnt += (running / total <= u) ? 1 : 0;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);

@@ -57,7 +57,7 @@ class A2CEngine:
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
 
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
-                 concurrent=True, chain_mode="auto", segments=None, persistent=True,
+                 concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
@@ -65,6 +65,7 @@ class A2CEngine:
         self.P, self.V, self.R = policy_params, value_params, reward_params
         self.gP, self.gV = policy_grads or {}, value_grads or {}
         self.concurrent = concurrent
+        self.want_entropy = entropy  # per-(step,row) policy entropy: a diagnostic, not part of the loss
         self.persistent = persistent  # persistent chain kernels (one launch for all steps) when the device can hold them
         assert chain_mode in ("auto", "exact", "segmented")
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
@@ -219,7 +220,7 @@ class A2CEngine:
                 hip.sample_tokens(ws["logits"], mode, tokT[k + 1], 1,
                                   uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
                                   log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
-                                  entropy=ws["entropy"][st] if mode != hip.GREEDY else None)
+                                  entropy=ws["entropy"][st] if (self.want_entropy and mode != hip.GREEDY) else None)
         self._mark("rollout_done")
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
@@ -257,7 +258,8 @@ class A2CEngine:
             if not ok_b:
                 bi = self._first_bwd = self._next_plan(plans, bi, bwd_checks)
         return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
-                             ws["rewards"].view(s, n).t().contiguous(), ws["scalars"], ws["entropy"], ws["status"],
+                             ws["rewards"].view(s, n).t().contiguous(), ws["scalars"],
+                             ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pf, pb))
 
     def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan, plan_bwd):

@@ -41,7 +41,7 @@ def build_modules(cfg):
 
 
 def run_step(a2c, rew, features, captions, p0, steps, **kw):
-    engine = trainers.build_engine(a2c, rew)
+    engine = trainers.build_engine(a2c, rew, entropy=True)
     feats = torch.as_tensor(features).float().cuda().contiguous()
     prefix = torch.as_tensor(np.asarray(captions)[:, :p0]).long().cuda()
     return engine.step(feats, prefix, steps, **kw).check()
