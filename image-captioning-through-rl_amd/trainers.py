@@ -19,7 +19,7 @@ from .engine import A2CEngine
 from .models import (MAX_SEQ_LEN, AdvantageActorCriticNetwork, PolicyNetwork, RewardNetwork, ValueNetwork,
                      device)
 from .optim import FusedAdam, flatten_module
-from .utilities import get_coco_minibatches, global_minibatch_number, print_green, save_a2c_model
+from .utilities import get_coco_minibatches, global_minibatch_number, minibatches, print_green, save_a2c_model
 
 H = 512
 
@@ -138,7 +138,7 @@ def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, s
     best_loss = float('inf')
     for epoch in range(epochs):
         for minibatch_id, (captions, features, _) in enumerate(
-                get_coco_minibatches(train_data, batch_size=batch_size, split='train')):
+                minibatches(train_data, batch_size=batch_size, split='train')):
             caplen = caption_length(captions)
             res = _a2c_minibatch(engine, optimizer, captions, features, 1, caplen - 1).check()
             loss, _, _, mean_reward, mean_adv = res.scalars[:5].tolist()
@@ -166,7 +166,7 @@ def a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, 
         print_green(f'[Training] Training curriculum level: {level}')
         for epoch in range(epochs):
             for minibatch_id, (captions, features, _) in enumerate(
-                    get_coco_minibatches(train_data, batch_size=batch_size, split='train')):
+                    minibatches(train_data, batch_size=batch_size, split='train')):
                 curr_seq_len = caption_length(captions) - level
                 if curr_seq_len >= 1:
                     res = _a2c_minibatch(engine, optimizer, captions, features, curr_seq_len, level).check()

@@ -34,28 +34,41 @@ def get_coco_minibatches(data, batch_size=100, split='train'):
 
 
 class DeviceFeatureStore:
-    """The feature matrix resident in HBM, so a minibatch's features are a coalesced
-    device row gather instead of a host gather + PCIe copy per step."""
+    """The feature matrix resident in HBM: a minibatch's features are a coalesced device row gather
+    (icrl_gather_rows) instead of the host gather + PCIe copy per step of get_coco_minibatches
+    (utilities.py:160-178).  Captions stay on the host (the training loops read their length there)."""
 
     def __init__(self, data, split='train', dev=None):
         dev = device if dev is None else dev
-        self.features = torch.as_tensor(data['%s_features' % split]).float().to(dev).contiguous()
-        self.image_idxs = torch.as_tensor(np.asarray(data['%s_image_idxs' % split])).long().to(dev)
-        self.captions = torch.as_tensor(np.asarray(data['%s_captions' % split])).long().to(dev)
+        self.split = split
+        self.features = torch.as_tensor(np.asarray(data['%s_features' % split])).float().to(dev).contiguous()
+        self.image_idxs = np.asarray(data['%s_image_idxs' % split])
+        self.captions = np.asarray(data['%s_captions' % split])
+        self.urls = data.get('%s_urls' % split)
 
     def minibatches(self, batch_size):
-        """Same order as get_coco_minibatches under the same torch seed; yields device
-        tensors (captions [n,L] int64, features [n,F] float32)."""
+        """Same order and rows as get_coco_minibatches under the same torch seed (one randperm draw);
+        yields (captions [n,L] host array, features [n,F] float32 device tensor, urls or None)."""
         from . import hipabi as hip
         total = self.captions.shape[0]
-        permutation = randperm(total).to(self.captions.device)
+        permutation = randperm(total)
         for i in range(0, total, batch_size):
-            mask = permutation[i: i + batch_size]
-            caps = self.captions[mask]
-            idx = self.image_idxs[mask].contiguous()
-            feats = torch.empty(idx.numel(), self.features.shape[1], device=self.features.device)
+            mask = permutation[i: i + batch_size].numpy()
+            idx_np = self.image_idxs[mask]
+            idx = torch.as_tensor(idx_np).long().to(self.features.device)
+            feats = torch.empty(idx.numel(), self.features.shape[1], dtype=torch.float32, device=self.features.device)
             hip.gather_rows(self.features, idx, 1, idx.numel(), feats)
-            yield caps, feats
+            urls = None if self.urls is None else np.asarray(self.urls)[idx_np]
+            yield self.captions[mask], feats, urls
+
+
+def minibatches(data, batch_size=100, split='train'):
+    """get_coco_minibatches, or the device-resident store when the data dict carries one under
+    'feature_store' (built once by the caller: data['feature_store'] = DeviceFeatureStore(data))."""
+    store = data.get('feature_store') if hasattr(data, 'get') else None
+    if store is not None and store.split == split:
+        return store.minibatches(batch_size)
+    return get_coco_minibatches(data, batch_size=batch_size, split=split)
 
 
 def global_minibatch_number(epoch, batch_id, batch_size):

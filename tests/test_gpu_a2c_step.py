@@ -22,6 +22,7 @@ hip = importlib.import_module("image-captioning-through-rl_amd.hipabi")
 models = importlib.import_module("image-captioning-through-rl_amd.models")
 trainers = importlib.import_module("image-captioning-through-rl_amd.trainers")
 optim = importlib.import_module("image-captioning-through-rl_amd.optim")
+utilities = importlib.import_module("image-captioning-through-rl_amd.utilities")
 
 RTOL, ATOL = 2e-4, 2e-5
 
@@ -127,6 +128,38 @@ def test_a2c_training_entry_point_two_minibatches():
     np.testing.assert_allclose(got2, g["scalars_step2"], rtol=1e-3, atol=1e-5)
     for k, p in a2c.named_parameters():
         check_summary(g, "param2", k, p.data.cpu().numpy(), 1e-5, 3e-6)
+
+
+def test_device_feature_store_yields_the_reference_minibatches():
+    """The HBM-resident feature store against get_coco_minibatches (utilities.py:160-178) under the same
+    torch seed: same order, same rows bit for bit, a ragged last batch and repeated image indices included;
+    and a2c_training fed from the store logs what the golden run of the reference logged."""
+    rs = np.random.RandomState(11)
+    data = {"train_captions": rs.randint(4, 50, size=(23, 17)), "train_image_idxs": rs.randint(0, 9, size=23),
+            "train_features": rs.standard_normal((9, 640)).astype(np.float32),
+            "train_urls": np.array(["u%d" % i for i in range(9)])}
+    store = utilities.DeviceFeatureStore(data)
+    torch.manual_seed(5)
+    want = list(utilities.get_coco_minibatches(data, batch_size=8))
+    torch.manual_seed(5)
+    got = list(store.minibatches(8))
+    assert [len(w[0]) for w in want] == [len(g_[0]) for g_ in got] == [8, 8, 7]
+    for (wc, wf, wu), (gc, gf, gu) in zip(want, got):
+        assert np.array_equal(wc, gc) and np.array_equal(wu, gu)
+        assert gf.is_cuda and np.array_equal(gf.cpu().numpy(), wf)
+
+    g = load_golden("a2c_n4_v100_l10_f512_s0")
+    cfg = g["cfg"]
+    a2c, rew = build_modules(cfg)
+    opt = optim.FusedAdam(optim.flatten_module(a2c), lr=1e-4)
+    data = synthetic.make_train_data(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    data["feature_store"] = utilities.DeviceFeatureStore(data)
+    log = trainers.ScalarLog()
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    trainers.a2c_training(data, a2c, rew, opt, log, [], cfg["n"], 2)
+    np.testing.assert_allclose(np.array([r[1] for r in log.records[:3]]), g["scalars_step1"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(np.array([r[1] for r in log.records[3:6]]), g["scalars_step2"], rtol=1e-3, atol=1e-5)
 
 
 def test_curriculum_entry_point_and_skip():
