@@ -64,14 +64,43 @@ using namespace icrl::seg;
     LSTM_BWD1(w, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
 
 // ------------------------------------------------------------------ forward step (LSTM: G = 4, GRU: G = 3)
+// GRU (three gate tiles): a wave per gate would leave a SIMD idle, so all four waves work on every
+// 64-k stage instead, wave q taking the 16-k group q of each of the three gates (three accumulators,
+// 24 MFMAs per stage and wave instead of 32); the waves' partial tiles are summed in LDS.
+struct FragK { float4 a0, a1, b[3][2]; };
+__device__ __forceinline__ void mfma8g(f32x16& acc, const FragK& f, int gq) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.x, f.b[gq][0].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.y, f.b[gq][0].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.z, f.b[gq][0].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0.w, f.b[gq][0].w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.x, f.b[gq][1].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.y, f.b[gq][1].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.z, f.b[gq][1].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1.w, f.b[gq][1].w, acc, 0, 0, 0);
+}
+// a_row / b_row: this lane's rows of the stage (h row l31; W_hh row l31 of gate 0), `gate` floats between
+// gates, o0 / o1: float offsets of the lane's two 16-byte chunks within a row
+__device__ __forceinline__ FragK load_frag_k(const float* a_row, const float* b_row, int gate, int o0, int o1) {
+    FragK f;
+    f.a0 = ld4(a_row + o0); f.a1 = ld4(a_row + o1);
+#pragma unroll
+    for (int gq = 0; gq < 3; ++gq) { f.b[gq][0] = ld4(b_row + gq * gate + o0); f.b[gq][1] = ld4(b_row + gq * gate + o1); }
+    return f;
+}
+// sum of the four waves' partial tiles of one gate: P[wave][gate][32][PLD]
+__device__ __forceinline__ float4 sum_partials(const float* p) {
+    constexpr int W = 3 * 32 * PLD;
+    return add4(add4(ldp4(p), ldp4(p + W)), add4(ldp4(p + 2 * W), ldp4(p + 3 * W)));
+}
+
 template <int G>
-__global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__ h_cur, const float* __restrict__ w_hh,
+__global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_cur, const float* __restrict__ w_hh,
                                                        const float* __restrict__ xproj, const float* __restrict__ b_hh,
                                                        const float* __restrict__ c_cur, float* __restrict__ c_nxt,
                                                        float* __restrict__ h_nxt, float* __restrict__ saved,
                                                        float* __restrict__ h_emit, float* __restrict__ seam_a,
                                                        float* __restrict__ seam_b, Geom g, int m) {
-    constexpr int NT = G * 64;                 // threads
+    constexpr int NT = 256;                    // threads
     constexpr int ROWS = 32 + G * 32;          // stage rows: 32 of H, then G x 32 of W_hh
     constexpr int F4 = ROWS * (BK / 4);        // float4 per stage
     constexpr int PER = (F4 + NT - 1) / NT;
@@ -132,9 +161,12 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
     constexpr int NK = H / BK;
     constexpr int DEPTH = 3;
     float4 ring[DEPTH][PER];
-    f32x16 acc;
+    constexpr int NACC = (G == 3) ? 3 : 1;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     if (m > 0) {  // the first step starts from a zero state: nothing to multiply
 #pragma unroll
@@ -148,38 +180,69 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
             for (int i = 0; i < PER; ++i) ring[0][i] = ld4(src[i] + DEPTH * BK);
         }
         __syncthreads();
+        constexpr int BUF = ROWS * LDT;
         const float* a_row = lds + l31 * LDT;
-        const float* b_row = lds + (32 + q * 32 + l31) * LDT;
-        Frag f0 = load_frag(a_row, b_row, 0, hh), f1;
+        if constexpr (G == 3) {
+            const float* b_row = lds + (32 + l31) * LDT;
+            const int o0 = 16 * q + 8 * hh, o1 = o0 + 4;
+            FragK f = load_frag_k(a_row, b_row, 32 * LDT, o0, o1), fn;
 #pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-            constexpr int BUF = ROWS * LDT;
-            const int co = (kt & 1) * BUF, cn = ((kt + 1) & 1) * BUF;
-            f1 = load_frag(a_row + co, b_row + co, 1, hh);
-            mfma8(acc, f0);
-            if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+            for (int kt = 0; kt < NK; ++kt) {
+                const int cn = ((kt + 1) & 1) * BUF;
+                if (kt + 1 < NK) {   // the previous stage's barrier came after the last read of buffer `cn`
 #pragma unroll
-                for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + cn + dst[i], ring[(kt + 1) % DEPTH][i]);
-                if (kt + 1 + DEPTH < NK) {
+                    for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + cn + dst[i], ring[(kt + 1) % DEPTH][i]);
+                    if (kt + 1 + DEPTH < NK) {
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) ring[(kt + 1) % DEPTH][i] = ld4(src[i] + (kt + 1 + DEPTH) * BK);
+                        for (int i = 0; i < PER; ++i) ring[(kt + 1) % DEPTH][i] = ld4(src[i] + (kt + 1 + DEPTH) * BK);
+                    }
                 }
+                mfma8g(acc[0], f, 0);
+                mfma8g(acc[1], f, 1);
+                if (kt + 1 < NK) {
+                    __syncthreads();
+                    fn = load_frag_k(a_row + cn, b_row + cn, 32 * LDT, o0, o1);
+                }
+                mfma8g(acc[2], f, 2);
+                f = fn;
             }
-            f0 = load_frag(a_row + co, b_row + co, 2, hh);
-            mfma8(acc, f1);
-            f1 = load_frag(a_row + co, b_row + co, 3, hh);
-            mfma8(acc, f0);
-            if (kt + 1 < NK) {
-                __syncthreads();
-                f0 = load_frag(a_row + cn, b_row + cn, 0, hh);
+        } else {
+            const float* b_row = lds + (32 + q * 32 + l31) * LDT;
+            Frag f0 = load_frag(a_row, b_row, 0, hh), f1;
+#pragma unroll
+            for (int kt = 0; kt < NK; ++kt) {
+                const int co = (kt & 1) * BUF, cn = ((kt + 1) & 1) * BUF;
+                f1 = load_frag(a_row + co, b_row + co, 1, hh);
+                mfma8(acc[0], f0);
+                if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) if (dst[i] >= 0) st4(lds + cn + dst[i], ring[(kt + 1) % DEPTH][i]);
+                    if (kt + 1 + DEPTH < NK) {
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) ring[(kt + 1) % DEPTH][i] = ld4(src[i] + (kt + 1 + DEPTH) * BK);
+                    }
+                }
+                f0 = load_frag(a_row + co, b_row + co, 2, hh);
+                mfma8(acc[0], f1);
+                f1 = load_frag(a_row + co, b_row + co, 3, hh);
+                mfma8(acc[0], f0);
+                if (kt + 1 < NK) {
+                    __syncthreads();
+                    f0 = load_frag(a_row + cn, b_row + cn, 0, hh);
+                }
+                mfma8(acc[0], f1);
             }
-            mfma8(acc, f1);
         }
         __syncthreads();  // every wave is done reading before the gate tiles overlay the stage buffers
     }
-    // gate tiles meet in LDS: P[gate][segment row][unit]
+    // gate tiles meet in LDS: LSTM P[gate][segment row][unit]; GRU P[wave][gate][segment row][unit] partials
     float* P = lds;
-    acc_to_lds(acc, P + q * 32 * PLD, l31, hh);
+    if constexpr (G == 3) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) acc_to_lds(acc[gq], P + (q * 3 + gq) * 32 * PLD, l31, hh);
+    } else {
+        acc_to_lds(acc[0], P + q * 32 * PLD, l31, hh);
+    }
     __syncthreads();
 
 #pragma unroll
@@ -212,8 +275,9 @@ __global__ __launch_bounds__(G * 64) void seg_fwd_step(const float* __restrict__
             if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
         } else {
             const float4 xr_ = px[ii][0], xz = px[ii][1], xn = px[ii][2];
-            const float4 hr_ = add4(ldp4(pr), ld4(b_hh + u)), hz = add4(ldp4(pr + 32 * PLD), ld4(b_hh + H + u));
-            const float4 hn = add4(ldp4(pr + 64 * PLD), ld4(b_hh + 2 * H + u));
+            const float4 hr_ = add4(sum_partials(pr), ld4(b_hh + u));
+            const float4 hz = add4(sum_partials(pr + 32 * PLD), ld4(b_hh + H + u));
+            const float4 hn = add4(sum_partials(pr + 64 * PLD), ld4(b_hh + 2 * H + u));
             GRU_CELL4(xr_, xz, xn, hr_, hz, hn, pprev[ii], h)
         }
         st4(h_nxt + (int64_t)j * H + u, h);
@@ -490,8 +554,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
 #pragma unroll
         for (int e = 0; e < 2; ++e) fo.o[grp][e] = 4 * ((4 * grp + 2 * hh + e) ^ (l31 & 15));
     const float* a_row = lds + l31 * BK;
-    const float* b_row = lds + (32 + (q < G ? q : 0) * 32 + l31) * BK;
-    const bool mm = q < G;   // a GRU step has three gate tiles: the fourth wave only stages
+    const float* b_row = lds + (32 + (q < G ? q : 0) * 32 + l31) * BK;   // LSTM: wave q owns gate q
 
     // this thread's epilogue item: segment row j, units u..u+3; its cell state lives in registers
     const int rr = tid >> 3, uq = 4 * (tid & 7);
@@ -523,9 +586,12 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
             }
         }
 
-        f32x16 acc;
+        constexpr int NACC = (G == 3) ? 3 : 1;
+        f32x16 acc[NACC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int a_ = 0; a_ < NACC; ++a_)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a_][r] = 0.f;
 
         if (m > 0) {
             constexpr int NK = H / BK;
@@ -564,30 +630,59 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
             STORE_STAGE(0, 0)
             if (PDEPTH < NK) LOAD_STAGE(0, PDEPTH)
             __syncthreads();
-            Frag f0, f1;
-            if (mm) f0 = load_frag_swz(a_row, b_row, fo, 0);
+            if constexpr (G == 3) {
+                const float* b_row0 = lds + (32 + l31) * BK;
+                const int o0 = fo.o[q][0], o1 = fo.o[q][1];
+                FragK f = load_frag_k(a_row, b_row0, 32 * BK, o0, o1), fn;
 #pragma unroll
-            for (int kt = 0; kt < NK; ++kt) {
-                const int co = (kt & 1) * PBUF, cn = ((kt + 1) & 1) * PBUF;
-                if (mm) { f1 = load_frag_swz(a_row + co, b_row + co, fo, 1); mfma8(acc, f0); }
-                if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
-                    STORE_STAGE(cn, (kt + 1) % PDEPTH)
-                    if (kt + 1 + PDEPTH < NK) LOAD_STAGE((kt + 1) % PDEPTH, kt + 1 + PDEPTH)
+                for (int kt = 0; kt < NK; ++kt) {
+                    const int cn = ((kt + 1) & 1) * PBUF;
+                    if (kt + 1 < NK) {   // the previous stage's barrier came after the last read of buffer `cn`
+                        STORE_STAGE(cn, (kt + 1) % PDEPTH)
+                        if (kt + 1 + PDEPTH < NK) LOAD_STAGE((kt + 1) % PDEPTH, kt + 1 + PDEPTH)
+                    }
+                    mfma8g(acc[0], f, 0);
+                    mfma8g(acc[1], f, 1);
+                    if (kt + 1 < NK) {
+                        __syncthreads();
+                        fn = load_frag_k(a_row + cn, b_row0 + cn, 32 * BK, o0, o1);
+                    }
+                    mfma8g(acc[2], f, 2);
+                    f = fn;
                 }
-                if (mm) { f0 = load_frag_swz(a_row + co, b_row + co, fo, 2); mfma8(acc, f1); }
-                if (mm) { f1 = load_frag_swz(a_row + co, b_row + co, fo, 3); mfma8(acc, f0); }
-                if (kt + 1 < NK) {
-                    __syncthreads();
-                    if (mm) f0 = load_frag_swz(a_row + cn, b_row + cn, fo, 0);
+            } else {
+                Frag f0 = load_frag_swz(a_row, b_row, fo, 0), f1;
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) {
+                    const int co = (kt & 1) * PBUF, cn = ((kt + 1) & 1) * PBUF;
+                    f1 = load_frag_swz(a_row + co, b_row + co, fo, 1);
+                    mfma8(acc[0], f0);
+                    if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+                        STORE_STAGE(cn, (kt + 1) % PDEPTH)
+                        if (kt + 1 + PDEPTH < NK) LOAD_STAGE((kt + 1) % PDEPTH, kt + 1 + PDEPTH)
+                    }
+                    f0 = load_frag_swz(a_row + co, b_row + co, fo, 2);
+                    mfma8(acc[0], f1);
+                    f1 = load_frag_swz(a_row + co, b_row + co, fo, 3);
+                    mfma8(acc[0], f0);
+                    if (kt + 1 < NK) {
+                        __syncthreads();
+                        f0 = load_frag_swz(a_row + cn, b_row + cn, fo, 0);
+                    }
+                    mfma8(acc[0], f1);
                 }
-                if (mm) mfma8(acc, f1);
             }
 #undef STORE_STAGE
 #undef LOAD_STAGE
             __syncthreads();  // every wave is done reading before the gate tiles overlay the stage buffers
         }
         float* P = lds;
-        if (mm) acc_to_lds(acc, P + q * 32 * PLD, l31, hh);
+        if constexpr (G == 3) {
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq) acc_to_lds(acc[gq], P + (q * 3 + gq) * 32 * PLD, l31, hh);
+        } else {
+            acc_to_lds(acc[0], P + q * 32 * PLD, l31, hh);
+        }
         __syncthreads();
 
         if (st != 0) {
@@ -609,8 +704,8 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                     if (pos == seg_beg - 1) st4(a.seam_a + (int64_t)j * 2 * H + H + u, c);
                     if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
                 } else {
-                    const float4 hr_ = add4(ldp4(pr), bias[0]), hz = add4(ldp4(pr + 32 * PLD), bias[1]);
-                    const float4 hn = add4(ldp4(pr + 64 * PLD), bias[G == 3 ? 2 : 0]);
+                    const float4 hr_ = add4(sum_partials(pr), bias[0]), hz = add4(sum_partials(pr + 32 * PLD), bias[1]);
+                    const float4 hn = add4(sum_partials(pr + 64 * PLD), bias[G == 3 ? 2 : 0]);
                     GRU_CELL4(px[0], px[1], px[2], hr_, hz, hn, state, h)
                     state = h;
                 }
@@ -886,7 +981,7 @@ extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, con
     const int steps = g.W + g.Ls;
     for (int m = 0; m < steps; ++m) {
         const int cur = m & 1;
-        hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(192), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
+        hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
                            (float*)nullptr, hb[cur ^ 1], (float*)nullptr, h_emit, seam_a, seam_b, g, m);
     }
     hipLaunchKernelGGL(seam_check_fwd, dim3((g.K * H + 255) / 256), dim3(256), 0, st, seam_a, seam_b, g, H, seam_err);
