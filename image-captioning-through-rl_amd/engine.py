@@ -138,7 +138,9 @@ class A2CEngine:
             return 0
         if self.segments:
             return int(self.segments)
-        return max(2, min(512, positions // 128))
+        # a step costs about the same for 32 segments as for 512 (fixed per-step time dominates until the
+        # device is full), so short chains are cut finer: fewer, fuller steps
+        return max(32, min(512, positions // 16 // 32 * 32))
 
     def _plans(self, ws):
         k = ws["segments"]
