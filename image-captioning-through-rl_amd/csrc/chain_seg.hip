@@ -22,6 +22,8 @@
 //   backward : [32 segments] x [32 units] tile of dh = dgates . W_hh per workgroup; the four
 //              waves split the 2048 gate rows (k), their partial tiles are summed in LDS,
 //              the cell's backward runs in the epilogue and writes the next step's dgates.
+#include <algorithm>
+
 #include "chain_seg_common.h"
 
 namespace {
@@ -288,22 +290,29 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
     }
 }
 
-// max over seams j >= 1 of |a - b| / max(1, |b|), `width` floats per seam
+// max over seams j >= 1 of |a - b| / max(1, |b|), `width` floats per seam.  Grid-stride, one atomic
+// per workgroup (thousands of atomics on one word cost ~100 us).
 __global__ __launch_bounds__(256) void seam_check_fwd(const float* __restrict__ seam_a, const float* __restrict__ seam_b,
                                                       Geom g, int width, float* __restrict__ err) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4];
     float d = 0.f;
-    if (e < g.K * width) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < g.K * width; e += gridDim.x * 256) {
         const int j = e / width;
         // seam j exists when segment j has positions and was warmed up from a zero state
         if (j >= 1 && (int64_t)j * g.Ls < g.total && (int64_t)j * g.Ls - g.W > 0) {
             const float a = seam_a[e], b = seam_b[e];
-            d = fabsf(a - b) / fmaxf(1.f, fabsf(b));
-            if (!(d == d)) d = INFINITY;
+            float v = fabsf(a - b) / fmaxf(1.f, fabsf(b));
+            if (!(v == v)) v = INFINITY;
+            d = fmaxf(d, v);
         }
     }
     d = wave_max(d);
-    if ((threadIdx.x & 63) == 0 && d > 0.f) atomic_max_nonneg(err, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (d > 0.f) atomic_max_nonneg(err, d);
+    }
 }
 
 // ------------------------------------------------------------------ LSTM backward step
@@ -442,25 +451,29 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
 __global__ __launch_bounds__(256) void seam_check_bwd(const float* __restrict__ seam_a, const float* __restrict__ dh_fin,
                                                       const float* __restrict__ dc, Geom g,
                                                       float* __restrict__ err_abs, float* __restrict__ ref_abs) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8];
     float d = 0.f, r = 0.f;
-    if (e < g.K * 2 * H) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < g.K * 2 * H; e += gridDim.x * 256) {
         const int j = e / (2 * H), k = e % (2 * H);
         if (j + 1 < g.K && (int64_t)(j + 1) * g.Ls + g.W < g.total) {
             const float b = (k < H) ? dh_fin[(int64_t)(j + 1) * H + k] : dc[(int64_t)(j + 1) * H + (k - H)];
-            d = fabsf(seam_a[e] - b);
-            r = fabsf(b);
-            if (!(d == d)) d = INFINITY;
+            float v = fabsf(seam_a[e] - b);
+            if (!(v == v)) v = INFINITY;
+            d = fmaxf(d, v);
+            r = fmaxf(r, fabsf(b));
         }
     }
     d = wave_max(d);
     r = wave_max(r);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = d; red[4 + (threadIdx.x >> 6)] = r; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        r = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         if (d > 0.f) atomic_max_nonneg(err_abs, d);
         if (r > 0.f) atomic_max_nonneg(ref_abs, r);
     }
 }
-
 
 // ------------------------------------------------------------------ persistent forward pair
 // Both forward chains (value LSTM, reward GRU) in ONE launch that walks every step.  Workgroups
@@ -929,6 +942,8 @@ __global__ void poison_on_abort1(const unsigned* abort_w, float* seam) {
 __global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* seam_r) {
     if (*abort_w != 0) { *seam_v = INFINITY; *seam_r = INFINITY; }
 }
+int seam_blocks(int64_t elems) { return (int)std::min<int64_t>(128, (elems + 255) / 256); }
+
 }  // namespace
 
 extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64_t)segments * 16 * H; }
@@ -956,7 +971,7 @@ extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, in
         hipLaunchKernelGGL(seg_fwd_step<4>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, (const float*)nullptr,
                            cb[cur], cb[cur ^ 1], hb[cur ^ 1], saved, h_emit, seam_a, seam_b, g, m);
     }
-    hipLaunchKernelGGL(seam_check_fwd, dim3((g.K * 2 * H + 255) / 256), dim3(256), 0, st, seam_a, seam_b, g, 2 * H,
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, seam_a, seam_b, g, 2 * H,
                        seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
@@ -984,7 +999,7 @@ extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, con
         hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
                            (float*)nullptr, hb[cur ^ 1], (float*)nullptr, h_emit, seam_a, seam_b, g, m);
     }
-    hipLaunchKernelGGL(seam_check_fwd, dim3((g.K * H + 255) / 256), dim3(256), 0, st, seam_a, seam_b, g, H, seam_err);
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * H)), dim3(256), 0, st, seam_a, seam_b, g, H, seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -1012,7 +1027,7 @@ extern "C" int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, co
                            dgates, seam_a, dh_fin, g, mp, 0);
     hipLaunchKernelGGL(seg_bwd_step, grid, dim3(256), 0, st, dg[(steps & 1) ^ 1], w_hh, saved, d_emit, dc,
                        dg[steps & 1], dgates, seam_a, dh_fin, g, steps, 1);
-    hipLaunchKernelGGL(seam_check_bwd, dim3((g.K * 2 * H + 255) / 256), dim3(256), 0, st, seam_a, dh_fin, dc, g,
+    hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, seam_a, dh_fin, dc, g,
                        seam_err, seam_err + 1);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
@@ -1060,9 +1075,9 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     unsigned* abort_w = words + 2 * ny * 16;
     const int per_chain = (H / 32) * ny;
     hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, abort_w, per_chain);
-    hipLaunchKernelGGL(seam_check_fwd, dim3((v.g.K * 2 * H + 255) / 256), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(v.g.K * 2 * H)), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
                        2 * H, seam_err_v);
-    hipLaunchKernelGGL(seam_check_fwd, dim3((r.g.K * H + 255) / 256), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(r.g.K * H)), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
                        seam_err_r);
     hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err_v, seam_err_r);
     ICRL_LAUNCH_CHECK();
@@ -1091,7 +1106,7 @@ extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* s
     a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
     unsigned* abort_w = words + ny * 16;
     hipLaunchKernelGGL(seg_bwd_persist, dim3(16 * ny), dim3(256), 0, st, a, abort_w);
-    hipLaunchKernelGGL(seam_check_bwd, dim3((a.g.K * 2 * H + 255) / 256), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
+    hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
                        a.g, seam_err, seam_err + 1);
     hipLaunchKernelGGL(poison_on_abort1, dim3(1), dim3(1), 0, st, abort_w, seam_err);
     ICRL_LAUNCH_CHECK();

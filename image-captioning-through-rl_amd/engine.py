@@ -115,13 +115,15 @@ class A2CEngine:
             sync_r=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
             status=torch.zeros(4, dtype=torch.int32, device=dev),
             # backward
-            dY=f32(s * n, 512), dYsum=f32(n, 512), d_emit=f32(s, n, H), dgv=f32(tv, 4 * H), hprev=f32(tv, H),
+            dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H), dgv=f32(tv, 4 * H), hprev=f32(tv, H),
             dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev),
             dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
             dX=f32(t_steps * n, e), tv=tv,
             seam=torch.zeros(6, dtype=torch.float32, device=dev), dlogits=f32(s, n, v),
-            scratch_main=f32(max(16 * 4 * H * H, 2 * s * n * H, 3 * v * H)),
-            scratch_side=f32(max(16 * 4 * H * H, 2 * s * n * H, 3 * v * H)),
+            # split-K partial slabs: up to 16 of a [4H,H] weight gradient, 8 of the vocabulary projection's,
+            # 5 of an activation gradient
+            scratch_main=f32(max(16 * 4 * H * H, 8 * v * H, 5 * l_cols * n * max(H, e, ev))),
+            scratch_side=f32(max(16 * 4 * H * H, 8 * v * H, 5 * l_cols * n * max(H, e, ev))),
         )
         k = self._segments_for(tv)
         if k:
@@ -352,10 +354,12 @@ class A2CEngine:
         dvalue = ws["dvalue"].view(s * n, 1)
         dY = ws["dY"]
         hip.gemm(dvalue, V["linear2.weight"], dY, b_kmajor=True)                       # dY = dvalue (x) w2
-        hip.gemm(dvalue, ws["Y"], gV["linear2.weight"], a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
+        sm = ws["scratch_main"]   # the two long-k weight gradients are split over k (partial slabs in scratch)
+        hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], sm, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
         hip.colsum(dvalue, gV["linear2.bias"])
         w1, gw1 = V["linear1.weight"], gV["linear1.weight"]
-        hip.gemm(dY, ws["hv"].view(s * n, H), gw1[:, self.F:], a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], sm, a_kmajor=True, b_kmajor=True)
+        gw1[:, self.F:].copy_(ws["gw1h"])
         hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1))
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
         hip.colsum(dY, gV["linear1.bias"])
@@ -422,31 +426,31 @@ class A2CEngine:
         hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G, tok_flat[p0 * n:], 1, ws["dlogp"])
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
         ss = ws["scratch_side"]
-        hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True)
         hip.colsum(G, gP["linear2vocab.bias"])
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
-        hip.gemm_auto(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), ss, b_kmajor=True)
+        hip.gemm_auto(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), ss, b_kmajor=True, shared=True)
         dgp = ws["dgp"]
         dc = [ws["dc0"], ws["dc1"]]
         for k in range(t_steps - 1, -1, -1):
             hip.lstm_cell_bwd(ws["gates"][k], ws["Cbuf"][k], ws["Cbuf"][k + 1], dHall[k],
                               None if k == t_steps - 1 else dc[(k + 1) & 1], dgp[k], dc[k & 1])
             if k > 0:
-                hip.gemm_auto(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], ss, b_kmajor=True, accumulate=True)
+                hip.gemm_auto(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], ss, b_kmajor=True, accumulate=True, shared=True)
             else:
-                hip.gemm_auto(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], ss, b_kmajor=True)
+                hip.gemm_auto(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], ss, b_kmajor=True, shared=True)
         dg_all = dgp.view(t_steps * n, 4 * H)
-        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True, shared=True)
         hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,
-                      b_kmajor=True)
+                      b_kmajor=True, shared=True)
         hip.colsum(dg_all, gP["lstm.bias_ih_l0"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
-            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True)
+            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True)
             g_emb.zero_()
             hip.scatter_add_rows(g_emb, tok_flat, 1, t_steps * n, ws["dX"])
-        hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"])

@@ -289,31 +289,54 @@ def sum_slabs(slabs, out, accumulate=False):
            "icrl_sum_slabs")
 
 
-def plan_gemm(m, n, k, out_contiguous=True):
-    """(tile, splits) for an [m,n,k] product, from measurements on MI355X: 64x64 tiles when the
-    k loop is short or the output is small (then split k so that ~1000 workgroups exist),
-    128x64 tiles for big outputs with a long k.  tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64."""
+def plan_gemm(m, n, k, out_contiguous=True, shared=False):
+    """(tile, splits) for an [m,n,k] product, from measurements on MI355X (tools/gemm_sweep.py).
+    shared: the launch will run beside a persistent chain kernel that holds half of every CU's LDS and
+    registers; only the smaller tiles co-reside with it in useful numbers, so the 128x128 choice below,
+    faster on an empty device, is not made.
+    tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64.  Short k loops: 64x64 tiles.  Small outputs: 64x64
+    tiles, k split so that about a thousand workgroups exist.  Otherwise 128x128 tiles with the split
+    that best fills the 256 CUs: a CU's last, partly filled turn costs as much as a full one, few
+    workgroups per CU leave pipeline fill and drain exposed, and every split costs a partial slab."""
     t64 = ((m + 63) // 64) * ((n + 63) // 64)
     if k <= 1024:
         return 3, 1
-    if t64 <= 512:
+    if not out_contiguous:
+        return (3 if t64 <= 512 else 2), 1
+    t128 = ((m + 127) // 128) * ((n + 127) // 128)
+    if shared and t64 > 512:
+        t2 = ((m + 127) // 128) * ((n + 63) // 64)
+        return 2, (2 if (t2 < 1024 and k >= 4096) else 1)
+    if t128 < 32 or shared:
         want = (2048 if k >= 32768 else 1024) // t64
-        splits = max(1, min(k // 512, want, 16)) if out_contiguous else 1
+        splits = max(1, min(k // 512, want, 16))
         return (1 if (k >= 32768 and splits > 1) else 3), splits
-    t2 = ((m + 127) // 128) * ((n + 63) // 64)
-    splits = 2 if (t2 < 1024 and k >= 4096 and out_contiguous) else 1
-    return 2, splits
+    ideal_us = 2.0 * m * n * k / 110e6
+    best = None
+    for splits in (1, 2, 3, 4, 5, 6, 8, 12, 16):   # the measured set
+        if splits > 1 and k // splits < 384:
+            break
+        per_cu = t128 * splits / 256.0
+        balance = per_cu / -(-per_cu // 1)
+        est = ideal_us / (balance * per_cu / (per_cu + 0.5))
+        if splits > 1:
+            est += splits * m * n * 8.0 / 7e6
+        if best is None or est < best[0]:
+            best = (est, splits)
+    return 1, best[1]
 
 
-def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None):
+def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None, shared=False):
     """gemm() with the tile / split-K choice of plan_gemm(); `scratch` is a flat float32 buffer for
     the split-K partial slabs (summed in a fixed order, so results are reproducible)."""
     m = a.shape[1] if a_kmajor else a.shape[0]
     k = a.shape[0] if a_kmajor else a.shape[1]
     n = b.shape[1] if b_kmajor else b.shape[0]
     contiguous = out.is_contiguous() and bias is None
-    tile, splits = plan_gemm(m, n, k, contiguous)
-    if splits > 1 and scratch is not None and scratch.numel() >= splits * m * n:
+    tile, splits = plan_gemm(m, n, k, contiguous, shared)
+    if splits > 1:  # no more partial slabs than the scratch buffer holds
+        splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
+    if splits > 1:
         slabs = scratch[:splits * m * n].view(splits, m, n)
         load().icrl_gemm_force_tile(tile)
         try:
