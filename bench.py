@@ -149,13 +149,22 @@ def main():
     # [segments, 512] x [512, G*512] product; the chain events above time those launches
     seg_flops = 0.0
     plan_fwd, plan_bwd = res.chain_plan
+    flops_of = {}
     for kind, gates, p0, plan in (("lstm_chain_fwd", 4, 1, plan_fwd), ("gru_chain_fwd", 3, 2, plan_fwd),
                                   ("lstm_chain_bwd", 4, 1, plan_bwd)):
         if plan[0] == "segmented":
             _, segs, warm = plan
             positions = hip.chain_positions(n, p0, steps_per_rollout)
             launches = warm + (positions + segs - 1) // segs
-            seg_flops += launches * 2.0 * segs * 512 * gates * 512
+            flops_of[kind] = launches * 2.0 * segs * 512 * gates * 512
+            seg_flops += flops_of[kind]
+    if "lstm_chain_fwd" in flops_of:
+        flops_of["chain_pair_fwd"] = flops_of["lstm_chain_fwd"] + flops_of["gru_chain_fwd"]
+    for kind, entry in chains.items():
+        if kind in flops_of:   # the segment-parallel kernels are f32 MFMA kernels: price them like the GEMM
+            tf = flops_of[kind] / (entry["ms_per_minibatch"] * 1e-3) / 1e12
+            entry.update({"gflop_per_minibatch": flops_of[kind] / 1e9, "achieved_tflops": tf,
+                          "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS})
     step_s = elapsed / args.steps
 
     if rank == 0:
