@@ -188,6 +188,45 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
     }
 }
 
+
+// Top-k of every row, descending (torch.topk(logits, k) of trainers.py:96): the row is staged in LDS,
+// then k rounds of a workgroup-wide argmax (ties: lowest index) that masks its winner.
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ logits, int64_t ld, int V, int k,
+                                                   float* __restrict__ values, int64_t* __restrict__ indices) {
+    extern __shared__ __attribute__((aligned(16))) float row[];  // V floats
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    const float* src = logits + (int64_t)r * ld;
+    for (int j = tid; j < V; j += 256) row[j] = src[j];
+    __syncthreads();
+    for (int round = 0; round < k; ++round) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < V; j += 256) {
+            const float v = row[j];
+            if (v > best) { best = v; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        for (int w = 0; w < 4; ++w)
+            if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
+        if (tid == 0) {
+            values[(int64_t)r * k + round] = best;
+            indices[(int64_t)r * k + round] = (int64_t)(bi == 0x7fffffff ? 0 : bi);
+            if (bi != 0x7fffffff) row[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int mode,
@@ -218,6 +257,18 @@ extern "C" int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N,
             icrl::set_error("icrl_sample_tokens: unknown mode %d", mode);
             return ICRL_ERR_ARG;
     }
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_topk_rows(const float* logits, int64_t ld_logits, int N, int V, int k, float* values,
+                              int64_t* indices, icrl_stream_t stream) {
+    ICRL_REQUIRE(logits && values && indices && N > 0 && V > 0, "icrl_topk_rows: null pointer or empty shape");
+    ICRL_REQUIRE(ld_logits >= V, "icrl_topk_rows: ld_logits < V");
+    ICRL_REQUIRE(k >= 1 && k <= 64 && k <= V, "icrl_topk_rows: k must be in [1, min(64, V)] (got %d)", k);
+    ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_topk_rows: vocabulary %d exceeds the 16384-entry LDS row", V);
+    hipLaunchKernelGGL(topk_kernel, dim3(N), dim3(256), (size_t)V * sizeof(float), icrl::as_stream(stream), logits,
+                       ld_logits, V, k, values, indices);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -27,6 +27,7 @@ SIGNATURES = {
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp] * 8),
@@ -202,6 +203,17 @@ def sample_tokens(logits, mode, tokens_out, token_stride, *, uniforms=None, log_
     _check(load().icrl_sample_tokens(_ptr(logits), logits.stride(0), n, v, mode, _ptr(uniforms), _ptr(tokens_out),
                                      token_stride, _ptr(log_prob), log_prob_stride, _ptr(probs), _ptr(entropy),
                                      _stream()), "icrl_sample_tokens")
+
+
+def topk_rows(logits, k):
+    """(values [N,k] float32, indices [N,k] int64) of the k largest entries per row, descending."""
+    n, v = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    values = torch.empty(n, k, dtype=torch.float32, device=logits.device)
+    indices = torch.empty(n, k, dtype=torch.int64, device=logits.device)
+    _check(load().icrl_topk_rows(_ptr(logits), logits.stride(0), n, v, k, _ptr(values), _ptr(indices), _stream()),
+           "icrl_topk_rows")
+    return values, indices
 
 
 def policy_dlogits(probs, dlogits, tokens, token_stride, coef):

@@ -19,7 +19,8 @@ from .engine import A2CEngine
 from .models import (MAX_SEQ_LEN, AdvantageActorCriticNetwork, PolicyNetwork, RewardNetwork, ValueNetwork,
                      device)
 from .optim import FusedAdam, flatten_module
-from .utilities import get_coco_minibatches, global_minibatch_number, minibatches, print_green, save_a2c_model
+from .utilities import (decode_captions, get_coco_batch, get_coco_minibatches, global_minibatch_number, minibatches,
+                        print_green, save_a2c_model)
 
 H = 512
 
@@ -73,6 +74,71 @@ def GenerateCaptionsGreedy(features, captions, policy_network):
             hip.gemm(h, policy_network.linear2vocab.weight, logits, bias=policy_network.linear2vocab.bias)
             hip.sample_tokens(logits, hip.GREEDY, tok_t[t + 1], 1)
     return tok_t.t().contiguous()
+
+
+@torch.no_grad()
+def GenerateCaptionsWithActorCriticLookAhead(features, captions, policy_network, value_network, beamSize=5,
+                                             most_likely=False):
+    """Beam look-ahead decoding (trainers.py:73-105): every step each kept candidate is extended by the
+    beamSize highest-scoring next words of the policy network; an extension is scored
+    0.6 * value(features, caption) + 0.4 * log(its logit) per row, scores accumulate with a minus sign
+    and the beamSize candidates with the lowest batch-mean score survive.  Candidates are whole-batch
+    captions [N, len].  As in the reference the "probabilities" handed to the logarithm are the raw
+    logits (a negative one gives NaN), the value network's recurrent state is never reset inside this
+    function (the order of its calls matters) and the ranking is Python's stable sort of the means.
+    Returns the list of (captions [N,17] int64, score [N,1]) pairs, or the first caption matrix."""
+    dev = policy_network.cnn2linear.weight.device
+    feats = torch.as_tensor(features, device=dev).float().contiguous()
+    caps0 = captions[:, 0:1] if torch.is_tensor(captions) else np.asarray(captions)[:, 0:1]
+    gen_caps = torch.as_tensor(caps0, device=dev).long()
+    candidates = [(gen_caps, 0)]
+    for _ in range(MAX_SEQ_LEN - 1):
+        next_candidates = []
+        for cand, cand_score in candidates:
+            logits = policy_network(feats.unsqueeze(0), cand)[:, -1, :].contiguous()
+            top_vals, top_words = hip.topk_rows(logits, beamSize)
+            for i in range(beamSize):
+                cap = torch.cat((cand, top_words[:, i:i + 1]), dim=1)
+                value = value_network(feats, cap)
+                score_delta = 0.6 * value + 0.4 * torch.log(top_vals[:, i:i + 1])
+                next_candidates.append((cap, cand_score - score_delta))
+        means = [float(c[1].mean()) for c in next_candidates]       # one read-back per candidate
+        order = sorted(range(len(next_candidates)), key=lambda j: means[j])
+        candidates = [next_candidates[j] for j in order[:beamSize]]
+    if most_likely:
+        return candidates[0][0]
+    return candidates
+
+
+def test_a2c_network(a2c_network, test_data, image_caption_data, data_size, validation_batch_size=128):
+    """Decode a random validation sample with the look-ahead beam and append real captions, generated
+    captions and image urls to the three result files (trainers.py:619-665; the slices of
+    validation_batch_size - 1 rows and the missing newline between batches are the reference's)."""
+    a2c_network.train(False)
+    real_f = open(image_caption_data["real_captions_path"], "a")
+    gen_f = open(image_caption_data["generated_captions_path"], "a")
+    url_f = open(image_caption_data["image_urls_path"], "a")
+    try:
+        captions_all, features_all, urls_all = get_coco_batch(test_data, batch_size=data_size, split='val')
+        for i in range(0, len(captions_all), validation_batch_size):
+            features_real = features_all[i:i + validation_batch_size - 1]
+            captions_real = captions_all[i:i + validation_batch_size - 1]
+            urls = urls_all[i:i + validation_batch_size - 1]
+            gen_cap = GenerateCaptionsWithActorCriticLookAhead(features_real, captions_real,
+                                                               a2c_network.policy_network,
+                                                               a2c_network.value_network, most_likely=True)
+            real_f.write("\n".join(decode_captions(captions_real, idx_to_word=test_data["idx_to_word"])))
+            gen_f.write("\n".join(decode_captions(gen_cap, idx_to_word=test_data["idx_to_word"])))
+            url_f.write("\n".join(urls))
+            for f in (real_f, gen_f, url_f):
+                f.flush()
+            a2c_network.value_network.valrnn.init_hidden()
+    finally:
+        for f in (real_f, gen_f, url_f):
+            f.close()
+
+
+test_a2c_network.__test__ = False  # a reference entry point, not a pytest case
 
 
 def GetRewards(features, captions, reward_network):

@@ -1,5 +1,5 @@
-"""The parts of the reference's utilities.py that the A2C training path calls:
-minibatch iteration, checkpoint save / load, logging helpers.  Dataset readers, word
+"""The parts of the reference's utilities.py that the A2C training path and the look-ahead test
+loop call: minibatch iteration, caption decoding, checkpoint save / load, logging helpers.  Dataset readers, word
 embedding tooling, metrics and post-processing are not part of this path."""
 import os
 
@@ -16,6 +16,35 @@ def print_green(text):
 
 def print_red(text):
     print('\033[31m', text, '\033[0m', sep='')
+
+
+def decode_captions(captions, idx_to_word):
+    """Token ids -> strings, dropping <NULL> and stopping after <END> (utilities.py:116-140)."""
+    captions = np.asarray(captions.cpu() if torch.is_tensor(captions) else captions)
+    singleton = captions.ndim == 1
+    if singleton:
+        captions = captions[None]
+    decoded = []
+    for row in captions:
+        words = []
+        for tok in row:
+            word = idx_to_word[int(tok)]
+            if word != '<NULL>':
+                words.append(word)
+            if word == '<END>':
+                break
+        decoded.append(' '.join(words))
+    return decoded[0] if singleton else decoded
+
+
+def get_coco_batch(data, batch_size=100, split='train'):
+    """One random batch (with replacement, NumPy's global stream): (captions, features, urls)
+    (utilities.py:143-157)."""
+    split_total_size = data['%s_captions' % split].shape[0]
+    mask = np.random.choice(split_total_size, batch_size)
+    captions = data['%s_captions' % split][mask]
+    image_idxs = data['%s_image_idxs' % split][mask]
+    return captions, data['%s_features' % split][image_idxs], data['%s_urls' % split][image_idxs]
 
 
 def get_coco_minibatches(data, batch_size=100, split='train'):

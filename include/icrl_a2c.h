@@ -120,6 +120,12 @@ int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int
                        float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
                        icrl_stream_t stream);
 
+/* values[r, 0..k) / indices[r, 0..k) = the k largest entries of logits[r, 0..V) in descending order,
+ * ties by lowest index: torch.topk(output[:, -1:, :], beamSize) of the look-ahead decoder,
+ * trainers.py:96.  k <= 64, V <= 16384. */
+int icrl_topk_rows(const float* logits, int64_t ld_logits, int N, int V, int k, float* values,
+                   int64_t* indices, icrl_stream_t stream);
+
 /* d logits for the policy-gradient term from the saved softmax (dlogits may alias probs):
  * g[r, k] = coef[r] * ((k == token[r]) - p[r, k]),  coef = dLoss/dlog_prob. */
 int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, const int64_t* tokens,

@@ -264,6 +264,72 @@ def greedy_decode(policy, features, captions, max_seq_len=17, dtype=torch.float6
     return tokens.numpy(), margins
 
 
+def policy_last_logits(P, features, caption):
+    """PolicyNetwork.forward(features[None], caption)[:, -1, :] (models.py:71-84): the LSTM from
+    h0 = cnn2linear(features), c0 = 0 over every column of `caption` [N, len], last position projected."""
+    emb = P["caption_embedding.weight"]
+    wih_t, whh_t = P["lstm.weight_ih_l0"].t(), P["lstm.weight_hh_l0"].t()
+    bias = P["lstm.bias_ih_l0"] + P["lstm.bias_hh_l0"]
+    feats = torch.as_tensor(features, dtype=emb.dtype)
+    h = feats @ P["cnn2linear.weight"].t() + P["cnn2linear.bias"]
+    c = torch.zeros_like(h)
+    for t in range(caption.shape[1]):
+        h, c = _lstm_step(emb[caption[:, t]] @ wih_t + bias, h, c, whh_t)
+    return h @ P["linear2vocab.weight"].t() + P["linear2vocab.bias"]
+
+
+def value_call(Vp, feats, caption, state):
+    """One ValueNetwork.forward(features, caption) (models.py:166-180) continuing the batch-1 chain
+    from state = (h, c); returns (values [N], new state)."""
+    h, c = state
+    emb = Vp["valrnn.caption_embedding.weight"]
+    xp = emb[caption] @ Vp["valrnn.lstm.weight_ih_l0"].t() + Vp["valrnn.lstm.bias_ih_l0"] + Vp["valrnn.lstm.bias_hh_l0"]
+    whh_t = Vp["valrnn.lstm.weight_hh_l0"].t()
+    outs = None
+    for t in range(caption.shape[1]):
+        outs = []
+        for i in range(caption.shape[0]):
+            h, c = _lstm_step(xp[i, t][None], h, c, whh_t)
+            outs.append(h[0])
+    y = torch.cat((feats, torch.stack(outs, 0)), dim=1) @ Vp["linear1.weight"].t() + Vp["linear1.bias"]
+    return (y @ Vp["linear2.weight"].t() + Vp["linear2.bias"])[:, 0], (h, c)
+
+
+def lookahead_decode(policy, value, features, captions, beam=5, max_seq_len=17, dtype=torch.float64):
+    """GenerateCaptionsWithActorCriticLookAhead (trainers.py:73-105) restated: whole-batch candidates,
+    top-`beam` LOGITS per row as next words, score -= 0.6 * value + 0.4 * log(logit), stable sort by the
+    batch-mean score, keep `beam`; the value chain's state runs on through every call in call order.
+    Returns dict(tokens [beam, N, max_seq_len], scores [beam, N], state (h, c) after the last call,
+    logit_margin = smallest gap between consecutive entries of any row's top beam+1 logits,
+    score_margin = smallest gap between consecutive sorted candidate means among the first beam+1):
+    the decoded ids are only well-posed when both margins exceed the arithmetic's rounding error."""
+    P, Vp = to_t(policy, dtype), to_t(value, dtype)
+    feats = torch.as_tensor(features, dtype=dtype)
+    state = (torch.zeros(1, H, dtype=dtype), torch.zeros(1, H, dtype=dtype))
+    cands = [(torch.as_tensor(np.asarray(captions)[:, :1], dtype=torch.int64), 0.0)]
+    logit_margin, score_margin = float("inf"), float("inf")
+    with torch.no_grad():
+        for _ in range(max_seq_len - 1):
+            nxt = []
+            for cap, score in cands:
+                logits = policy_last_logits(P, feats, cap)
+                top_v, top_i = logits.topk(min(beam + 1, logits.shape[1]), dim=1)
+                logit_margin = min(logit_margin, float((top_v[:, :-1] - top_v[:, 1:]).min()))
+                for i in range(beam):
+                    cap_i = torch.cat((cap, top_i[:, i:i + 1]), dim=1)
+                    v, state = value_call(Vp, feats, cap_i, state)
+                    nxt.append((cap_i, score - (0.6 * v + 0.4 * torch.log(top_v[:, i]))))
+            means = [float(c[1].mean()) for c in nxt]
+            order = sorted(range(len(nxt)), key=lambda j: means[j])
+            ranked = [means[j] for j in order[:beam + 1]]
+            if len(ranked) > 1:
+                score_margin = min(score_margin, float(np.diff(ranked).min()))
+            cands = [nxt[j] for j in order[:beam]]
+    return {"tokens": np.stack([c[0].numpy() for c in cands]), "scores": np.stack([c[1].numpy() for c in cands]),
+            "state": (state[0][0].numpy(), state[1][0].numpy()),
+            "logit_margin": logit_margin, "score_margin": score_margin}
+
+
 def adam_update(params, grads, state, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.Adam (no amsgrad, no weight decay), in place on float64 copies.
     state: dict with 'step', 'm', 'v' (created on first use)."""

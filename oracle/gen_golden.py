@@ -11,7 +11,7 @@ empty placeholder modules are registered for those names; the tensorboard
 placeholder's SummaryWriter records the (tag, value, step) triples, which are the
 reference's per-minibatch outputs (trainers.py:489-492).
 
-Usage:  python oracle/gen_golden.py            (writes tests/golden/)
+Usage:  python oracle/gen_golden.py [--lookahead-only]           (writes tests/golden/)
 """
 import importlib
 import os
@@ -23,6 +23,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "image-captioning-through-rl_amd"))
 import synthetic  # noqa: E402
 
@@ -215,6 +216,28 @@ def golden_greedy(models, trainers, cfg):
             "greedy_margins": (top2[..., 0] - top2[..., 1]).numpy()}
 
 
+def golden_lookahead(models, trainers, cfg):
+    """The reference's beam look-ahead decoder (trainers.py:73-105) on seeded inputs: the five
+    surviving candidates with their scores, the value chain's state after its last call, and the
+    margins (from the float64 restatement) below which the decoded ids stop being well-posed."""
+    from oracle import a2c_oracle as orc
+    n, vocab, caplen, fdim, seed = cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"]
+    pol, val, _ = build_nets(models, vocab, fdim, seed)
+    feats, caps = synthetic.make_minibatch(n, vocab, caplen, fdim, seed)
+    with torch.no_grad():
+        cands = trainers.GenerateCaptionsWithActorCriticLookAhead(feats, caps, pol, val)
+    tokens = np.stack([c[0].numpy() for c in cands]).astype(np.int64)
+    scores = np.stack([c[1].numpy()[:, 0] for c in cands])
+    assert np.isfinite(scores).all(), "a negative logit reached the logarithm: pick another seed"
+    h, c = val.valrnn.hidden_cell
+    want = orc.lookahead_decode(synthetic.make_params("policy", vocab, fdim, seed),
+                                synthetic.make_params("value", vocab, fdim, seed), feats, caps)
+    assert np.array_equal(want["tokens"], tokens), "float64 restatement decodes other ids than the reference"
+    return {"cfg": np.array([n, vocab, caplen, fdim, seed]), "tokens": tokens, "scores": scores,
+            "final_h": h.detach().numpy().reshape(-1), "final_c": c.detach().numpy().reshape(-1),
+            "logit_margin": np.float64(want["logit_margin"]), "score_margin": np.float64(want["score_margin"])}
+
+
 CONFIGS = [
     dict(name="n4_v100_l10_f512_s0", n=4, vocab=100, caplen=10, fdim=512, seed=0),
     dict(name="n4_v100_l10_f512_s1", n=4, vocab=100, caplen=10, fdim=512, seed=1),
@@ -227,15 +250,23 @@ def main():
     models, trainers = import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
-    for cfg in CONFIGS:
+    for cfg in ([] if "--lookahead-only" in sys.argv else CONFIGS):
         out = golden_for(models, trainers, cfg)
         out.update(golden_greedy(models, trainers, cfg))
         np.savez_compressed(os.path.join(gdir, "a2c_%s.npz" % cfg["name"]), **out)
         print("wrote", cfg["name"], "loss", out["scalars_step1"])
-    cfg = dict(name="n4_v100_l10_f512_s0", n=4, vocab=100, caplen=10, fdim=512, seed=0)
-    out = golden_for(models, trainers, cfg, level=3)
-    np.savez_compressed(os.path.join(gdir, "a2c_curriculum3_%s.npz" % cfg["name"]), **out)
-    print("wrote curriculum level 3", out["scalars_step1"])
+    if "--lookahead-only" not in sys.argv:
+        cfg = dict(name="n4_v100_l10_f512_s0", n=4, vocab=100, caplen=10, fdim=512, seed=0)
+        out = golden_for(models, trainers, cfg, level=3)
+        np.savez_compressed(os.path.join(gdir, "a2c_curriculum3_%s.npz" % cfg["name"]), **out)
+        print("wrote curriculum level 3", out["scalars_step1"])
+    # seeds picked for the widest margins among a dozen tried: with ~10^4 logit comparisons per decode the
+    # smallest gap is ~1e-5 at best
+    for cfg in (dict(name="n4_v100_f512_s3", n=4, vocab=100, caplen=10, fdim=512, seed=3),
+                dict(name="n6_v257_f2048_s2", n=6, vocab=257, caplen=12, fdim=2048, seed=2)):
+        out = golden_lookahead(models, trainers, cfg)
+        np.savez_compressed(os.path.join(gdir, "lookahead_%s.npz" % cfg["name"]), **out)
+        print("wrote look-ahead", cfg["name"], "margins", out["logit_margin"], out["score_margin"])
 
 
 if __name__ == "__main__":

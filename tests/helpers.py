@@ -16,6 +16,7 @@ synthetic = importlib.import_module("image-captioning-through-rl_amd.synthetic")
 GOLDEN_A2C = ["a2c_n4_v100_l10_f512_s0", "a2c_n4_v100_l10_f512_s1",
               "a2c_n4_v100_l10_f4096_s0", "a2c_n8_v257_l20_f2048_s0"]
 GOLDEN_CURRICULUM = ["a2c_curriculum3_n4_v100_l10_f512_s0"]
+GOLDEN_LOOKAHEAD = ["lookahead_n4_v100_f512_s3", "lookahead_n6_v257_f2048_s2"]
 PROBES = 48
 
 
@@ -24,6 +25,13 @@ def load_golden(name):
     n, vocab, caplen, fdim, seed, level = [int(x) for x in g["cfg"]]
     g["cfg"] = dict(n=n, vocab=vocab, caplen=caplen, fdim=fdim, seed=seed,
                     level=None if level < 0 else level)
+    return g
+
+
+def load_lookahead(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    n, vocab, caplen, fdim, seed = [int(x) for x in g["cfg"]]
+    g["cfg"] = dict(n=n, vocab=vocab, caplen=caplen, fdim=fdim, seed=seed, level=None)
     return g
 
 

@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN_A2C, GOLDEN_CURRICULUM, check_summary, load_golden, params_for, synthetic
+from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, check_summary, load_golden, load_lookahead,
+                     params_for, synthetic)
 from oracle import a2c_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -103,6 +104,53 @@ def test_greedy_ids_bit_exact(name):
     assert toks.dtype == torch.int64 and tuple(toks.shape) == (cfg["n"], 17)
     assert g["greedy_margins"].min() > 1e-5
     assert np.array_equal(toks.cpu().numpy(), g["greedy_tokens"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_LOOKAHEAD)
+def test_lookahead_decoder_matches_reference(name, tmp_path):
+    """GenerateCaptionsWithActorCriticLookAhead on the HIP kernels against what the reference decoded
+    from the same seeded weights and inputs: the five candidates' ids exact (the fixture's margins are
+    checked first), their scores and the value chain's state after ~400 chained calls to rounding."""
+    g = load_lookahead(name)
+    cfg = g["cfg"]
+    assert g["logit_margin"] > 5e-6 and g["score_margin"] > 1e-4
+    a2c, _ = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    a2c.value_network.valrnn.init_hidden()
+    cands = trainers.GenerateCaptionsWithActorCriticLookAhead(feats, caps, a2c.policy_network, a2c.value_network)
+    assert len(cands) == 5
+    toks = np.stack([c[0].cpu().numpy() for c in cands])
+    assert toks.dtype == np.int64 and np.array_equal(toks, g["tokens"])
+    scores = np.stack([c[1].cpu().numpy()[:, 0] for c in cands])
+    np.testing.assert_allclose(scores, g["scores"], rtol=2e-4, atol=2e-4)
+    h, c = a2c.value_network.valrnn.hidden_cell
+    np.testing.assert_allclose(h.cpu().numpy().reshape(-1), g["final_h"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(c.cpu().numpy().reshape(-1), g["final_c"], rtol=1e-3, atol=2e-5)
+    a2c.value_network.valrnn.init_hidden()
+    best = trainers.GenerateCaptionsWithActorCriticLookAhead(feats, caps, a2c.policy_network, a2c.value_network,
+                                                             most_likely=True)
+    assert np.array_equal(best.cpu().numpy(), g["tokens"][0])
+
+
+def test_test_a2c_network_writes_the_three_files(tmp_path):
+    """The reference's test loop (trainers.py:619-665): rows of validation_batch_size - 1, one line per
+    caption, value chain reset between batches."""
+    g = load_lookahead(GOLDEN_LOOKAHEAD[0])
+    cfg = g["cfg"]
+    a2c, _ = build_modules(cfg)
+    data = synthetic.make_train_data(7, cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    test_data = {"val_captions": data["train_captions"], "val_image_idxs": data["train_image_idxs"],
+                 "val_features": data["train_features"], "val_urls": np.array(["url%d" % i for i in range(7)]),
+                 "idx_to_word": ["<NULL>", "<START>", "<END>", "<UNK>"] + ["w%d" % i for i in range(4, cfg["vocab"])]}
+    paths = {k: str(tmp_path / k) for k in ("real_captions_path", "generated_captions_path", "image_urls_path")}
+    np.random.seed(3)
+    trainers.test_a2c_network(a2c, test_data, paths, data_size=5, validation_batch_size=4)
+    real = open(paths["real_captions_path"]).read()
+    gen = open(paths["generated_captions_path"]).read()
+    urls = open(paths["image_urls_path"]).read()
+    # batches of 3 rows (rows 0-2 and 4: the reference's slice drops one row per batch), no newline between batches
+    assert real.count("\n") == gen.count("\n") == urls.count("\n") == 2
+    assert real.startswith("<START>") and gen.startswith("<START>") and "url" in urls
 
 
 def test_a2c_training_entry_point_two_minibatches():

@@ -419,3 +419,17 @@ def test_fused_policy_lstm_step_matches_the_unfused_kernels(n, e):
     np.testing.assert_allclose(gates.cpu().numpy(), act_w.numpy(), rtol=1e-5, atol=3e-6)
     np.testing.assert_allclose(c1.cpu().numpy(), c_w.numpy(), rtol=1e-5, atol=3e-6)
     np.testing.assert_allclose(h1.cpu().numpy(), h_w.numpy(), rtol=1e-5, atol=3e-6)
+
+
+# --------------------------------------------------------------------------- top-k
+@pytest.mark.parametrize("n,v,k", [(5, 100, 5), (64, 10000, 5), (3, 257, 8), (2, 16384, 1)])
+def test_topk_rows_matches_torch(n, v, k):
+    rs = np.random.RandomState(v + k)
+    x = dev(rnd(rs, n, v))
+    vals, idx = hip.topk_rows(x, k)
+    want_v, want_i = torch.topk(x, k, dim=1)
+    assert torch.equal(vals, want_v) and torch.equal(idx, want_i)
+    # ties: lowest index first
+    x[:, 7] = x[:, 3] = 100.0
+    vals, idx = hip.topk_rows(x, min(k, 2))
+    assert idx[:, 0].tolist() == [3] * n and (k == 1 or idx[:, 1].tolist() == [7] * n)

@@ -3,7 +3,8 @@
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_A2C, GOLDEN_CURRICULUM, check_summary, load_golden, params_for, synthetic
+from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, check_summary, load_golden, load_lookahead,
+                     params_for, synthetic)
 from oracle import a2c_oracle as orc
 
 # float64 oracle vs the reference's float32 arithmetic
@@ -66,6 +67,23 @@ def test_greedy_decode(name):
     assert g["greedy_margins"].min() > 1e-5, "fixture has a near-tie; regenerate with another seed"
     assert np.array_equal(tokens, g["greedy_tokens"])
     np.testing.assert_allclose(margins, g["greedy_margins"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", GOLDEN_LOOKAHEAD)
+def test_lookahead_decode(name):
+    """The restatement of the beam look-ahead decoder against what the reference itself decoded: ids
+    exact, scores and the value chain's final state to float32 rounding."""
+    g = load_lookahead(name)
+    cfg = g["cfg"]
+    pol, val, _ = params_for(cfg)
+    feats, caps = synthetic.make_minibatch(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    got = orc.lookahead_decode(pol, val, feats, caps)
+    assert got["tokens"].shape == (5, cfg["n"], 17)
+    assert g["logit_margin"] > 5e-6 and g["score_margin"] > 1e-4, "fixture has a near-tie; regenerate with another seed"
+    assert np.array_equal(got["tokens"], g["tokens"])
+    np.testing.assert_allclose(got["scores"], g["scores"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got["state"][0], g["final_h"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(got["state"][1], g["final_c"], rtol=1e-3, atol=2e-5)
 
 
 def test_two_step_training_matches_reference():
