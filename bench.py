@@ -5,8 +5,8 @@
 
 A "step" is one full a2c_training minibatch (trainers.py:426-496): policy rollout with
 sampling, value + reward chains, loss, backward through policy and value networks,
-gradient all-reduce across ranks (N > 1), Adam.  Workload = BASELINE.json configs[2]:
-batch 512 per GPU, 2048-d features, vocab 10k, caption length T = 20, float32 arithmetic.
+gradient all-reduce across ranks (N > 1), Adam.  Workload: the batch-512 configuration the
+headline metric is quoted on - batch 512 per GPU, 2048-d features, vocab 10k, caption length T = 20, float32 arithmetic.
 Inputs (features, start tokens, uniforms) are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.
 """
@@ -174,8 +174,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "A2C minibatch: batch %d per GPU, %d-d features, vocab %d, T=%d "
-                                   "(BASELINE.json configs[2]%s)" % (n, fdim, vocab, caplen,
-                                                                     "; configs[3] data-parallel" if world > 1 else ""),
+                                   "(the metric's batch-512 configuration%s)" % (n, fdim, vocab, caplen,
+                                                                     ", data-parallel over the GPUs" if world > 1 else ""),
                        "global_batch": world * n, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,

@@ -256,17 +256,16 @@ int launch(const GemmArgs& g, int a_km, int b_km, int splits, hipStream_t st) {
 }  // namespace
 
 namespace {
-int g_forced_tile = 0;
-
 int gemm_dispatch(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows, const float* B, int64_t ldb,
                   int b_kmajor, float* C, int64_t ldc, int M, int N, int K, const float* bias, const float* bias2,
-                  int accumulate, int splits, int64_t slab, hipStream_t st, const char* who) {
+                  int accumulate, int splits, int64_t slab, int tile, hipStream_t st, const char* who) {
     ICRL_REQUIRE(A && B && C, "%s: null operand", who);
     ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty shape %dx%dx%d", who, M, N, K);
     ICRL_REQUIRE(!(a_rows && a_kmajor), "%s: row gather needs a_kmajor = 0", who);
     ICRL_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N,
                  "%s: leading dimension smaller than the row length", who);
     ICRL_REQUIRE(splits >= 1 && splits <= 64, "%s: splits must be in [1, 64]", who);
+    ICRL_REQUIRE(tile >= 0 && tile <= 3, "%s: tile must be 0..3", who);
     GemmArgs g;
     g.A = A; g.lda = lda; g.a_rows = a_rows; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K; g.bias = bias; g.bias2 = bias2; g.accumulate = accumulate;
@@ -276,7 +275,6 @@ int gemm_dispatch(const float* A, int64_t lda, int a_kmajor, const int64_t* a_ro
     g.kchunk = ((ksteps + splits - 1) / splits) * BK;
     g.slab = slab;
     const int64_t big_tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * splits;
-    int tile = g_forced_tile;
     if (tile == 0) tile = (big_tiles >= 256 && K > 1024) ? 2 : 3;  // measured: 64x64 wins for short k loops
     if (tile == 1) return launch<128, 128>(g, a_kmajor, b_kmajor, splits, st);
     if (tile == 2) return launch<128, 64>(g, a_kmajor, b_kmajor, splits, st);
@@ -284,35 +282,27 @@ int gemm_dispatch(const float* A, int64_t lda, int a_kmajor, const int64_t* a_ro
 }
 }  // namespace
 
-// Tuning hook: 0 = choose by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64 output tiles.
-extern "C" int icrl_gemm_force_tile(int tile) {
-    ICRL_REQUIRE(tile >= 0 && tile <= 3, "icrl_gemm_force_tile: tile must be 0..3");
-    g_forced_tile = tile;
-    return ICRL_OK;
-}
-
-
 namespace icrl {
 // Used by the host-side chain schedules in this library.
 int gemm(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
          int64_t ldc, int M, int N, int K, int splits, int64_t slab, hipStream_t st) {
     return gemm_dispatch(A, lda, a_kmajor, nullptr, B, ldb, b_kmajor, C, ldc, M, N, K, nullptr, nullptr, 0,
-                         splits, slab, st, "icrl::gemm");
+                         splits, slab, 0, st, "icrl::gemm");
 }
 }  // namespace icrl
 
 extern "C" int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
                              const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
                              int M, int N, int K, const float* bias, const float* bias2,
-                             int accumulate, icrl_stream_t stream) {
+                             int accumulate, int tile, icrl_stream_t stream) {
     return gemm_dispatch(A, lda, a_kmajor, a_rows, B, ldb, b_kmajor, C, ldc, M, N, K, bias, bias2, accumulate, 1,
-                         0, icrl::as_stream(stream), "icrl_gemm_f32");
+                         0, tile, icrl::as_stream(stream), "icrl_gemm_f32");
 }
 
 extern "C" int icrl_gemm_f32_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
                                     int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M, int N,
-                                    int K, int splits, icrl_stream_t stream) {
+                                    int K, int splits, int tile, icrl_stream_t stream) {
     ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f32_splitk: slabs overlap");
     return gemm_dispatch(A, lda, a_kmajor, nullptr, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, nullptr, 0,
-                         splits, slab_stride, icrl::as_stream(stream), "icrl_gemm_f32_splitk");
+                         splits, slab_stride, tile, icrl::as_stream(stream), "icrl_gemm_f32_splitk");
 }

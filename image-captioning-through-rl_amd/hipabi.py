@@ -20,10 +20,9 @@ SIGNATURES = {
     "icrl_abi_version": (c_int, []),
     "icrl_last_error": (ctypes.c_char_p, []),
     "icrl_gemm_f32": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int,
-                              c_vp, c_vp, c_int, c_vp]),
-    "icrl_gemm_force_tile": (c_int, [c_int]),
+                              c_vp, c_vp, c_int, c_int, c_vp]),
     "icrl_gemm_f32_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
-                                     c_int, c_vp]),
+                                     c_int, c_int, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -136,8 +135,8 @@ def _f32c(t):
 
 
 def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, bias2=None, accumulate=False,
-         m=None, n=None, k=None, lda=None, ldb=None, ldc=None):
-    """out[M,N] (+)= A[M,K] @ B[K,N] (+ bias + bias2).
+         m=None, n=None, k=None, lda=None, ldb=None, ldc=None, tile=0):
+    """out[M,N] (+)= A[M,K] @ B[K,N] (+ bias + bias2).  tile: 0 = by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64.
 
     a: stored [M, K] (a_kmajor False) or [K, M] (True); b: stored [N, K] (False, an
     nn.Linear weight) or [K, N] (True).  2-D tensors whose last dimension is contiguous;
@@ -159,7 +158,8 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
         assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
     with _Timed("gemm", 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
         rc = load().icrl_gemm_f32(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor),
-                                  _ptr(out), ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), _stream())
+                                  _ptr(out), ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), int(tile),
+                                  _stream())
     _check(rc, "icrl_gemm_f32")
     return out
 
@@ -281,7 +281,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
            "icrl_adam_step")
 
 
-def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False):
+def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0):
     """slabs[z] = partial product of split z; slabs is [splits, M, N] contiguous."""
     m = a.shape[1] if a_kmajor else a.shape[0]
     k = a.shape[0] if a_kmajor else a.shape[1]
@@ -289,7 +289,7 @@ def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False):
     assert slabs.shape == (splits, m, n) and slabs.is_contiguous()
     with _Timed("gemm", 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
         rc = load().icrl_gemm_f32_splitk(_ptr(a), a.stride(0), int(a_kmajor), _ptr(b), b.stride(0), int(b_kmajor),
-                                         _ptr(slabs), n, m * n, m, n, k, splits, _stream())
+                                         _ptr(slabs), n, m * n, m, n, k, splits, int(tile), _stream())
     _check(rc, "icrl_gemm_f32_splitk")
 
 
@@ -350,19 +350,10 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:
         slabs = scratch[:splits * m * n].view(splits, m, n)
-        load().icrl_gemm_force_tile(tile)
-        try:
-            gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
-        finally:
-            load().icrl_gemm_force_tile(0)
+        gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor, tile=tile)
         sum_slabs(slabs, out, accumulate=accumulate)
         return out
-    load().icrl_gemm_force_tile(tile)
-    try:
-        gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias)
-    finally:
-        load().icrl_gemm_force_tile(0)
-    return out
+    return gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias, tile=tile)
 
 
 def chain_seg_workspace_floats(segments):

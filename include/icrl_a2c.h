@@ -46,15 +46,13 @@ const char* icrl_last_error(void);
  *   b_kmajor = 0: B stored [N][ldb] (k contiguous, an nn.Linear weight); 1: [K][ldb]
  *   a_rows: optional int64[M] row gather for A (a_kmajor = 0 only), i.e. the
  *           nn.Embedding lookup of models.py:73 fused into the product.
- *   bias, bias2: optional float[N]. */
+ *   bias, bias2: optional float[N].
+ *   tile: output tile per workgroup, 0 = chosen by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64
+ *         (a performance choice only; the caller plans it per shape and per what else runs). */
 int icrl_gemm_f32(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
                   const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
                   int M, int N, int K, const float* bias, const float* bias2,
-                  int accumulate, icrl_stream_t stream);
-
-/* Tuning hook for measurements: 0 = choose the output tile by shape (default), 1 = 128x128,
- * 2 = 128x64, 3 = 64x64.  Process-wide. */
-int icrl_gemm_force_tile(int tile);
+                  int accumulate, int tile, icrl_stream_t stream);
 
 /* Split-K form for products with a long k and a small output (the weight gradients
  * summed over ~10^5 chain positions; the per-step products of the segment-parallel chain):
@@ -63,7 +61,7 @@ int icrl_gemm_force_tile(int tile);
  * reproducible run to run, unlike float atomics). */
 int icrl_gemm_f32_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
                          int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
-                         int N, int K, int splits, icrl_stream_t stream);
+                         int N, int K, int splits, int tile, icrl_stream_t stream);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
 int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,

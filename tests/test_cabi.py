@@ -30,5 +30,5 @@ def test_library_reports_abi_version_and_errors_without_gpu():
     assert lib.icrl_abi_version() == hip.ABI_VERSION
     assert lib.icrl_chain_sync_bytes() >= 2 * 2048 * 8
     # argument validation happens before any HIP call, so it works on a CPU-only host
-    rc = lib.icrl_gemm_f32(None, 0, 0, None, None, 0, 0, None, 0, 1, 1, 1, None, None, 0, None)
+    rc = lib.icrl_gemm_f32(None, 0, 0, None, None, 0, 0, None, 0, 1, 1, 1, None, None, 0, 0, None)
     assert rc == -1 and b"null operand" in lib.icrl_last_error()

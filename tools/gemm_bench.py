@@ -9,9 +9,8 @@ def bench(name, m, n, k, a_km, b_km, splits=1):
     out = torch.empty(m, n, device="cuda"); slabs = torch.empty(max(splits,1), m, n, device="cuda")
     res = []
     for tile in (1, 2, 3):
-        lib.icrl_gemm_force_tile(tile)
         for sp in ([1] if splits == 1 else [1, splits]):
-            f = (lambda: hip.gemm(a, b, out, a_kmajor=a_km, b_kmajor=b_km)) if sp == 1 else (lambda: hip.gemm_splitk(a, b, slabs[:sp], sp, a_kmajor=a_km, b_kmajor=b_km))
+            f = (lambda: hip.gemm(a, b, out, a_kmajor=a_km, b_kmajor=b_km, tile=tile)) if sp == 1 else (lambda: hip.gemm_splitk(a, b, slabs[:sp], sp, a_kmajor=a_km, b_kmajor=b_km, tile=tile))
             for _ in range(3): f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -19,7 +18,6 @@ def bench(name, m, n, k, a_km, b_km, splits=1):
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100
             res.append("t%d/s%d: %7.1f us %5.1f TF" % (tile, sp, us, 2.0 * m * n * k / us / 1e6))
-    lib.icrl_gemm_force_tile(0)
     print("%-34s %s" % (name, " | ".join(res)), flush=True)
 bench("gates 512x2048x512 NT", 512, 2048, 512, False, False)
 bench("vocab 512x10000x512 NT", 512, 10000, 512, False, False)

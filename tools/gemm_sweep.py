@@ -29,18 +29,16 @@ def sweep(name, m, n, k, a_km, b_km, splits_list=(1, 2, 3, 4, 5, 6, 8, 12, 16)):
     slabs = torch.empty(max(splits_list), m, n, device="cuda")
     res = []
     for tile in (1, 2, 3):
-        lib.icrl_gemm_force_tile(tile)
         for sp in splits_list:
             if sp > 1 and k // sp < 256:
                 continue
             if sp == 1:
-                f = lambda: hip.gemm(a, b, out, a_kmajor=a_km, b_kmajor=b_km)
+                f = lambda tile=tile: hip.gemm(a, b, out, a_kmajor=a_km, b_kmajor=b_km, tile=tile)
             else:
-                def f(sp=sp):
-                    hip.gemm_splitk(a, b, slabs[:sp], sp, a_kmajor=a_km, b_kmajor=b_km)
+                def f(sp=sp, tile=tile):
+                    hip.gemm_splitk(a, b, slabs[:sp], sp, a_kmajor=a_km, b_kmajor=b_km, tile=tile)
                     hip.sum_slabs(slabs[:sp], out)
             res.append((time_us(f), tile, sp))
-    lib.icrl_gemm_force_tile(0)
     res.sort()
     cur = hip.plan_gemm(m, n, k)
     cur_us = [r[0] for r in res if (r[1], r[2]) == cur]
