@@ -200,6 +200,51 @@ __global__ __launch_bounds__(1024) void a2c_loss_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- pre-training losses
+// Length-weighted teacher-forced cross entropy (trainers.py:238-242): loss = sum_i weight[i] *
+// sum_{t < valid[i]} -logp[t, i]; d loss / d logp[t, i] = -weight[i] inside the mask, 0 outside.
+__global__ __launch_bounds__(1024) void masked_nll_kernel(const float* __restrict__ logp, const int* __restrict__ valid,
+                                                          const float* __restrict__ weight, int steps, int n,
+                                                          float* __restrict__ loss, float* __restrict__ d_logp) {
+    __shared__ double red[16];
+    double acc = 0.;
+    for (int e = threadIdx.x; e < steps * n; e += 1024) {
+        const int t = e / n, i = e % n;
+        const bool in = t < valid[i];
+        if (in) acc += (double)(-logp[e] * weight[i]);
+        if (d_logp) d_logp[e] = in ? -weight[i] : 0.f;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.;
+        for (int w = 0; w < 16; ++w) a += red[w];
+        loss[0] = (float)a;
+    }
+}
+
+// nn.MSELoss (mean) of values against targets (trainers.py:155, 178): loss and d loss / d values
+__global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ values, const float* __restrict__ targets,
+                                                        int count, float* __restrict__ loss, float* __restrict__ d_value) {
+    __shared__ double red[16];
+    double acc = 0.;
+    const float inv = 1.0f / (float)count;
+    for (int e = threadIdx.x; e < count; e += 1024) {
+        const float d = values[e] - targets[e];
+        acc += (double)(d * d);
+        if (d_value) d_value[e] = 2.f * d * inv;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.;
+        for (int w = 0; w < 16; ++w) a += red[w];
+        loss[0] = (float)(a / count);
+    }
+}
+
 // g[r,k] = coef[r] * (onehot(token[r])[k] - p[r,k]); g may alias p
 __global__ __launch_bounds__(256) void policy_dlogits_kernel(const float* p, float* g, int rows, int V,
                                                              const int64_t* __restrict__ tokens,
@@ -380,6 +425,25 @@ extern "C" int icrl_a2c_loss(const float* values, const float* rewards, const fl
                  "icrl_a2c_loss: null pointer or count <= 0");
     hipLaunchKernelGGL(a2c_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), values, rewards, log_probs,
                        count, scalars, d_value, d_logp);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_masked_nll(const float* log_probs, const int* valid_steps, const float* row_weight, int steps, int N,
+                               float* loss, float* d_logp, icrl_stream_t stream) {
+    ICRL_REQUIRE(log_probs && valid_steps && row_weight && loss && steps > 0 && N > 0,
+                 "icrl_masked_nll: null pointer or empty shape");
+    hipLaunchKernelGGL(masked_nll_kernel, dim3(1), dim3(1024), 0, as_stream(stream), log_probs, valid_steps, row_weight,
+                       steps, N, loss, d_logp);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_mse_loss(const float* values, const float* targets, int count, float* loss, float* d_value,
+                             icrl_stream_t stream) {
+    ICRL_REQUIRE(values && targets && loss && count > 0, "icrl_mse_loss: null pointer or count <= 0");
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), values, targets, count, loss,
+                       d_value);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -78,14 +78,26 @@ class A2CEngine:
         self.last_seam = None
         self._ws = {}
         self._side = None
-        dev = self.P["cnn2linear.weight"].device
-        self.device = dev
-        self.vocab, self.E = self.P["caption_embedding.weight"].shape
-        self.F = self.P["cnn2linear.weight"].shape[1]
-        assert self.P["cnn2linear.weight"].shape[0] == H
-        assert self.V["linear1.weight"].shape == (512, self.F + H), "value head width != feature_dim + 512"
-        assert self.R["visual_embed.weight"].shape == (512, self.F)
-        for group in (self.P, self.V, self.R):
+        # any subset of the three networks may be bound (the pre-training steps use one at a time)
+        self.P, self.V, self.R = self.P or None, self.V or None, self.R or None
+        groups = [g for g in (self.P, self.V, self.R) if g is not None]
+        assert groups, "no parameters given"
+        self.device = next(iter(groups[0].values())).device
+        self.vocab, self.E, self.F = None, None, None
+        if self.P is not None:
+            self.vocab, self.E = self.P["caption_embedding.weight"].shape
+            self.F = self.P["cnn2linear.weight"].shape[1]
+            assert self.P["cnn2linear.weight"].shape[0] == H
+        if self.V is not None:
+            f = self.V["linear1.weight"].shape[1] - H
+            assert self.V["linear1.weight"].shape[0] == 512 and (self.F is None or f == self.F), \
+                "value head width != feature_dim + 512"
+            self.F = f
+        if self.R is not None:
+            assert self.R["visual_embed.weight"].shape[0] == 512
+            assert self.F is None or self.R["visual_embed.weight"].shape[1] == self.F
+            self.F = self.R["visual_embed.weight"].shape[1]
+        for group in groups:
             for k, t in group.items():
                 assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), k
 
@@ -95,42 +107,50 @@ class A2CEngine:
         ws = self._ws.get(key)
         if ws is not None:
             return ws
-        dev, v, e, f = self.device, self.vocab, self.E, self.F
-        ev, er = self.V["valrnn.caption_embedding.weight"].shape[1], self.R["rewrnn.caption_embedding.weight"].shape[1]
+        dev = self.device
         t_steps, l_cols, lv = p0 - 1 + s, p0 + s, p0 + s - 1
         tv = n * sum(p0 + k for k in range(s))
 
         def f32(*shape):
             return torch.empty(*shape, dtype=torch.float32, device=dev)
 
-        ws = dict(
-            tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev),
-            Hbuf=f32(t_steps + 1, n, H), Cbuf=f32(t_steps + 1, n, H), gates=f32(t_steps, n, 4 * H),
-            X=f32(t_steps, n, e), logits=f32(n, v), probs=f32(s, n, v), logp=f32(s, n), entropy=f32(s, n),
-            Xv=f32(lv * n, ev), XPv=f32(lv * n, 4 * H), hv=f32(s, n, H), saved=f32(tv, 6, H), U=f32(n, 512),
-            Y=f32(s * n, 512), values=f32(s * n),
-            XPr=f32(l_cols * n, 3 * H), hr=f32(s, n, H), se=f32(s * n, 512), ve=f32(n, 512), rewards=f32(s * n),
-            scalars=torch.zeros(8, dtype=torch.float32, device=dev), dvalue=f32(s * n), dlogp=f32(s * n),
-            sync_v=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
-            sync_r=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
-            status=torch.zeros(4, dtype=torch.int32, device=dev),
-            # backward
-            dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H), dgv=f32(tv, 4 * H), hprev=f32(tv, H),
-            dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev),
-            dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
-            dX=f32(t_steps * n, e), tv=tv,
-            seam=torch.zeros(6, dtype=torch.float32, device=dev), dlogits=f32(s, n, v),
-            # split-K partial slabs: up to 16 of a [4H,H] weight gradient, 8 of the vocabulary projection's,
-            # 5 of an activation gradient
-            scratch_main=f32(max(16 * 4 * H * H, 8 * v * H, 5 * l_cols * n * max(H, e, ev))),
-            scratch_side=f32(max(16 * 4 * H * H, 8 * v * H, 5 * l_cols * n * max(H, e, ev))),
-        )
+        ws = dict(tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev), tv=tv,
+                  scalars=torch.zeros(8, dtype=torch.float32, device=dev),
+                  status=torch.zeros(4, dtype=torch.int32, device=dev),
+                  seam=torch.zeros(6, dtype=torch.float32, device=dev))
+        widths = [H]
+        if self.P is not None:
+            v, e = self.vocab, self.E
+            widths.append(e)
+            ws.update(
+                Hbuf=f32(t_steps + 1, n, H), Cbuf=f32(t_steps + 1, n, H), gates=f32(t_steps, n, 4 * H),
+                X=f32(t_steps, n, e), logits=f32(n, v), probs=f32(s, n, v), logp=f32(s, n), entropy=f32(s, n),
+                dlogp=f32(s * n), dlogits=f32(s, n, v),
+                dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
+                dX=f32(t_steps * n, e))
+            ws["Cbuf"][0].zero_()
+        if self.V is not None:
+            ev = self.V["valrnn.caption_embedding.weight"].shape[1]
+            widths.append(ev)
+            ws.update(
+                Xv=f32(lv * n, ev), XPv=f32(lv * n, 4 * H), hv=f32(s, n, H), saved=f32(tv, 6, H), U=f32(n, 512),
+                Y=f32(s * n, 512), values=f32(s * n), dvalue=f32(s * n),
+                sync_v=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
+                dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H), dgv=f32(tv, 4 * H),
+                hprev=f32(tv, H), dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev))
+        if self.R is not None:
+            ws.update(
+                XPr=f32(l_cols * n, 3 * H), hr=f32(s, n, H), se=f32(s * n, 512), ve=f32(n, 512), rewards=f32(s * n),
+                sync_r=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev))
+        # split-K partial slabs: up to 16 of a [4H,H] weight gradient, 8 of the vocabulary projection's,
+        # 5 of an activation gradient
+        scratch = max(16 * 4 * H * H, 8 * (self.vocab or 0) * H, 5 * l_cols * n * max(widths))
+        ws["scratch_main"], ws["scratch_side"] = f32(scratch), f32(scratch)
         k = self._segments_for(tv)
         if k:
             ws["work_v"] = f32(hip.chain_seg_workspace_floats(k))
             ws["work_r"] = f32(hip.chain_seg_workspace_floats(k))
         ws["segments"] = k
-        ws["Cbuf"][0].zero_()
         self._ws[key] = ws
         return ws
 
@@ -180,6 +200,75 @@ class A2CEngine:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _rollout(self, ws, features, n, p0, s, uniforms, mode):
+        """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
+        from column to column, only the newest position projected to the vocabulary and sampled (or
+        arg-maxed, or scored against the forced token)."""
+        P = self.P
+        t_steps = p0 - 1 + s
+        tokT = ws["tokT"]
+        Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
+        hip.gemm(features, P["cnn2linear.weight"], Hb[0], bias=P["cnn2linear.bias"])
+        fused_step = self.E % 64 == 0
+        for k in range(t_steps):
+            if fused_step:  # gather + both gate products + cell in one launch
+                hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k], P["lstm.weight_ih_l0"],
+                                     P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k], Cb[k],
+                                     gates[k], Cb[k + 1], Hb[k + 1], X[k])
+            else:
+                hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
+                hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"],
+                         bias2=P["lstm.bias_hh_l0"])
+                hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True)
+                hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
+            if k >= p0 - 1:
+                st = k - (p0 - 1)
+                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"])
+                hip.sample_tokens(ws["logits"], mode, tokT[k + 1], 1,
+                                  uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
+                                  log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
+                                  entropy=ws["entropy"][st] if (self.want_entropy and mode != hip.GREEDY) else None)
+
+    # ------------------------------------------------------------------ pre-training steps
+    def policy_ce_step(self, features, captions, valid_steps, row_weight):
+        """Teacher-forced cross-entropy step of the policy pre-training loop (trainers.py:228-252):
+        captions [N, L] int64 cuda; position t < valid_steps[i] of row i contributes
+        -row_weight[i] * log p(captions[i, t+1] | captions[i, :t+1]).  Fills the policy gradients;
+        returns the loss as a 1-element device tensor."""
+        n, l_cols = captions.shape
+        s = l_cols - 1
+        ws = self._buffers(n, 1, s)
+        ws["tokT"].copy_(captions.t())
+        self._rollout(ws, features, n, 1, s, None, hip.FORCED)
+        hip.masked_nll(ws["logp"], valid_steps, row_weight, ws["scalars"][0:1], ws["dlogp"])
+        self._policy_backward(ws, features, n, 1, s)
+        return ws["scalars"][0:1]
+
+    def value_mse_step(self, features, captions, targets):
+        """Mean-squared-error step of the value pre-training loop (trainers.py:175-190): one
+        ValueNetwork call on captions [N, p] (its batch-1 chain walked exactly), nn.MSELoss against
+        targets [N], gradients of the value network.  Returns (loss 1-element tensor, values [N])."""
+        V, gV = self.V, self.gV
+        n, p0 = captions.shape
+        ws = self._buffers(n, p0, 1)
+        main = torch.cuda.current_stream()
+        ws["tokT"][:p0].copy_(captions.t())
+        tok_flat = ws["tokT"].view(-1)
+        hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, p0 * n, ws["Xv"])
+        hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
+                 bias2=V["valrnn.lstm.bias_hh_l0"])
+        hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, 1, ws["hv"], ws["saved"], ws["sync_v"],
+                           ws["status"][0:1])
+        w1 = V["linear1.weight"]
+        hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
+        hip.gemm(ws["hv"].view(n, H), w1[:, self.F:], ws["Y"])
+        hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], n, n, ws["values"])
+        hip.mse_loss(ws["values"], targets, ws["scalars"][0:1], ws["dvalue"])
+        self._value_head_backward(ws, features, n, 1)
+        hip.chain_hprev(ws["saved"], ws["tv"], ws["hprev"])
+        self._value_chain_backward(ws, n, p0, 1, main, main, ("exact",), None)
+        return ws["scalars"][0:1], ws["values"]
+
     # ------------------------------------------------------------------ the step
     def step(self, features, prefix, n_steps, uniforms=None, forced_tokens=None, mode=hip.SAMPLE, backward=True):
         """features [N,F] float32 cuda; prefix [N,p0] int64 cuda (ground-truth start
@@ -203,28 +292,7 @@ class A2CEngine:
         main = torch.cuda.current_stream()
 
         self._mark("start")
-        # ---- 1. policy rollout (models.py:71-84 run incrementally; trainers.py:443-458)
-        Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
-        hip.gemm(features, P["cnn2linear.weight"], Hb[0], bias=P["cnn2linear.bias"])
-        fused_step = self.E % 64 == 0
-        for k in range(t_steps):
-            if fused_step:  # gather + both gate products + cell in one launch
-                hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k], P["lstm.weight_ih_l0"],
-                                     P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k], Cb[k],
-                                     gates[k], Cb[k + 1], Hb[k + 1], X[k])
-            else:
-                hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
-                hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"],
-                         bias2=P["lstm.bias_hh_l0"])
-                hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True)
-                hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
-            if k >= p0 - 1:
-                st = k - (p0 - 1)
-                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"])
-                hip.sample_tokens(ws["logits"], mode, tokT[k + 1], 1,
-                                  uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
-                                  log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
-                                  entropy=ws["entropy"][st] if (self.want_entropy and mode != hip.GREEDY) else None)
+        self._rollout(ws, features, n, p0, s, uniforms, mode)
         self._mark("rollout_done")
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
@@ -351,6 +419,13 @@ class A2CEngine:
         ev_loss.record(main)
 
         # ---- value network: head, then the chain's BPTT (main stream)
+        self._value_head_backward(ws, features, n, s)
+        self._value_chain_backward(ws, n, p0, s, main, side, plan, ev_loss, features)
+
+    def _value_head_backward(self, ws, features, n, s):
+        """Backward of the two linear layers of the value head (models.py:175-178) from ws["dvalue"]:
+        their weight gradients and d_emit, the gradient entering the chain at each call's last column."""
+        V, gV = self.V, self.gV
         dvalue = ws["dvalue"].view(s * n, 1)
         dY = ws["dY"]
         hip.gemm(dvalue, V["linear2.weight"], dY, b_kmajor=True)                       # dY = dvalue (x) w2
@@ -364,7 +439,6 @@ class A2CEngine:
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
         hip.colsum(dY, gV["linear1.bias"])
         hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
-        self._value_chain_backward(ws, n, p0, s, main, side, plan, ev_loss, features)
 
     def _value_chain_backward(self, ws, n, p0, s, main, side, plan, ev_loss, features=None):
         """The value chain's BPTT and everything that consumes it.  With ev_loss the side stream also

@@ -26,6 +26,8 @@ SIGNATURES = {
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_masked_nll": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "icrl_mse_loss": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -203,6 +205,19 @@ def sample_tokens(logits, mode, tokens_out, token_stride, *, uniforms=None, log_
     _check(load().icrl_sample_tokens(_ptr(logits), logits.stride(0), n, v, mode, _ptr(uniforms), _ptr(tokens_out),
                                      token_stride, _ptr(log_prob), log_prob_stride, _ptr(probs), _ptr(entropy),
                                      _stream()), "icrl_sample_tokens")
+
+
+def masked_nll(log_probs, valid_steps, row_weight, loss, d_logp=None):
+    """log_probs [S, N] float32; valid_steps [N] int32; row_weight [N] float32; loss: 1-element view."""
+    s_, n = log_probs.shape
+    assert valid_steps.dtype == torch.int32 and row_weight.dtype == torch.float32
+    _check(load().icrl_masked_nll(_ptr(_f32c(log_probs)), _ptr(valid_steps), _ptr(row_weight), s_, n, _ptr(loss),
+                                  _ptr(d_logp), _stream()), "icrl_masked_nll")
+
+
+def mse_loss(values, targets, loss, d_value=None):
+    _check(load().icrl_mse_loss(_ptr(_f32c(values)), _ptr(_f32c(targets)), values.numel(), _ptr(loss), _ptr(d_value),
+                                _stream()), "icrl_mse_loss")
 
 
 def topk_rows(logits, k):

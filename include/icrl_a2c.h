@@ -237,6 +237,17 @@ int icrl_cosine_reward(const float* ve, const float* se, int rows, int N, float*
 int icrl_a2c_loss(const float* values, const float* rewards, const float* log_probs, int count,
                   float* scalars, float* d_value, float* d_logp, icrl_stream_t stream);
 
+/* Length-weighted teacher-forced cross entropy of the policy pre-training loop
+ * (trainers.py:238-242): loss[0] = sum_i row_weight[i] * sum_{t < valid_steps[i]} -log_probs[t*N+i];
+ * d_logp (optional) [steps*N] = -row_weight[i] inside the mask, 0 outside. */
+int icrl_masked_nll(const float* log_probs, const int* valid_steps, const float* row_weight, int steps, int N,
+                    float* loss, float* d_logp, icrl_stream_t stream);
+
+/* nn.MSELoss() of the value pre-training loop (trainers.py:155, 178): loss[0] = mean (v - t)^2,
+ * d_value (optional) = 2 (v - t) / count. */
+int icrl_mse_loss(const float* values, const float* targets, int count, float* loss, float* d_value,
+                  icrl_stream_t stream);
+
 /* ---- Adam (trainers.py:378, 480): torch.optim.Adam defaults, bias-corrected ---- */
 int icrl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    double lr, double beta1, double beta2, double eps, int step,
