@@ -114,6 +114,18 @@ def make_train_data(n_captions, vocab, caplen, feature_dim, seed, max_len=None):
     }
 
 
+def make_ragged_train_data(n_captions, vocab, feature_dim, seed, max_len=17):
+    """make_train_data with captions of different lengths (6 .. max_len tokens, <END> last, <NULL>
+    after it), as the pre-training loops meet them (trainers.py:238-242 weights rows by length)."""
+    data = make_train_data(n_captions, vocab, max_len, feature_dim, seed, max_len)
+    caps = data["train_captions"]
+    for i in range(n_captions):
+        length = max_len if i == 0 else 6 + (5 * i + seed) % (max_len - 6)
+        caps[i, length - 1] = 2
+        caps[i, length:] = 0
+    return data
+
+
 def make_uniforms(seed, count):
     """The doubles ``numpy.random.choice`` would consume after ``np.random.seed(seed)``:
     one ``random_sample()`` per call, in (step, row) order (trainers.py:447-449)."""

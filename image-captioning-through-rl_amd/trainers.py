@@ -248,6 +248,95 @@ def a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, 
     return a2c_network
 
 
+def _ce_weights(captions, steps):
+    """Per row: how many of the `steps` teacher-forced positions count, and the weight of each
+    (trainers.py:238-242: (caplen / N) * mean over the first caplen positions, slices clipped to the
+    positions that exist)."""
+    caps = np.asarray(captions)
+    n = caps.shape[0]
+    caplen = np.array([np.nonzero(caps[i] == 2)[0][0] + 1 for i in range(n)])
+    valid = np.minimum(caplen, steps)
+    return valid.astype(np.int32), (caplen / (n * valid)).astype(np.float32)
+
+
+def _save_if_best(loss, best_loss, network, path):
+    if loss < best_loss:
+        torch.save(network.state_dict(), path)
+        return loss
+    return best_loss
+
+
+def train_policy_network(train_data, network_paths, plot_dir, bidirectional, epochs=100, batch_size=512):
+    """Supervised pre-training of the policy network (trainers.py:202-257): teacher forcing, cross
+    entropy weighted by caption length, Adam(lr=1e-3); the parameters are saved whenever a minibatch
+    improves on the best loss seen (before that minibatch's update, as in the reference)."""
+    fdim = int(np.asarray(train_data["train_features"]).shape[1])
+    policy_network = PolicyNetwork(train_data["word_to_idx"], input_dim=fdim,
+                                   pretrained_embeddings=train_data["embeddings"], bidirectional=bidirectional).to(device)
+    flat = flatten_module(policy_network)
+    optimizer = FusedAdam(flat, lr=0.001)
+    engine = A2CEngine(_params_of(policy_network), None, None, _grads_of(policy_network))
+    writer = make_writer(plot_dir)
+    best_loss = float("inf")
+    print_green('[Training] Training Policy Network')
+    for epoch in range(epochs):
+        for minibatch_id, (captions, features, _) in enumerate(
+                minibatches(train_data, batch_size=batch_size, split='train')):
+            caps = torch.as_tensor(np.asarray(captions), device=device).long().contiguous()
+            feats = torch.as_tensor(features, device=device).float().contiguous()
+            valid, weight = _ce_weights(captions, caps.shape[1] - 1)
+            loss = engine.policy_ce_step(feats, caps, torch.from_numpy(valid).to(device),
+                                         torch.from_numpy(weight).to(device)).item()
+            best_loss = _save_if_best(loss, best_loss, policy_network, network_paths["policy_network"])
+            writer.add_scalar('Policy Network-loss', loss, global_minibatch_number(epoch, minibatch_id, batch_size))
+            ddp.average_gradients(flat.flat_grad)
+            optimizer.step()
+    return policy_network
+
+
+def train_value_network(train_data, network_paths, plot_dir, bidirectional, epochs=50, batch_size=512):
+    """Supervised pre-training of the value network (trainers.py:125-199): for each minibatch the
+    frozen policy network decodes greedily, the frozen reward network scores the result, and the value
+    network's estimate for a random-length prefix (random.randint(1, MAX_SEQ_LEN) columns) is regressed
+    on that reward with nn.MSELoss, Adam(lr=1e-3)."""
+    import random
+    w2i, emb = train_data["word_to_idx"], train_data["embeddings"]
+    fdim = int(np.asarray(train_data["train_features"]).shape[1])
+    reward_network = RewardNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device)
+    reward_network.load_state_dict(torch.load(network_paths["reward_network"], map_location=device, weights_only=True),
+                                   strict=False)
+    reward_network.train(False).requires_grad_(False)
+    policy_network = PolicyNetwork(w2i, input_dim=fdim, pretrained_embeddings=emb, bidirectional=bidirectional).to(device)
+    policy_network.load_state_dict(torch.load(network_paths["policy_network"], map_location=device, weights_only=True),
+                                   strict=False)
+    policy_network.train(False).requires_grad_(False)
+    value_network = ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device)
+    flat = flatten_module(value_network)
+    optimizer = FusedAdam(flat, lr=0.001)
+    engine = A2CEngine(None, _params_of(value_network), None, None, _grads_of(value_network))
+    writer = make_writer(plot_dir)
+    best_loss = float('inf')
+    print_green('[Training] Training Value Network')
+    for epoch in range(epochs):
+        for minibatch_id, (captions, features, _) in enumerate(
+                minibatches(train_data, batch_size=batch_size, split='train')):
+            feats = torch.as_tensor(features, device=device).float().contiguous()
+            gen_caps = GenerateCaptionsGreedy(feats, captions, policy_network)
+            rewards = GetRewards(feats, gen_caps, reward_network)
+            columns = random.randint(1, MAX_SEQ_LEN)
+            loss, _ = engine.value_mse_step(feats, gen_caps[:, :columns].contiguous(), rewards.view(-1))
+            loss = loss.item()
+            if int(engine._buffers(feats.shape[0], columns, 1)["status"].abs().sum()) != 0:
+                raise RuntimeError("a persistent chain kernel timed out")
+            best_loss = _save_if_best(loss, best_loss, value_network, network_paths["value_network"])
+            writer.add_scalar('Value Network-loss', loss, global_minibatch_number(epoch, minibatch_id, batch_size))
+            ddp.average_gradients(flat.flat_grad)
+            optimizer.step()
+            value_network.valrnn.init_hidden()
+            reward_network.rewrnn.init_hidden()
+    return value_network
+
+
 def _load_or_fail(net, path, what):
     try:
         net.load_state_dict(torch.load(path, map_location=device, weights_only=True), strict=False)

@@ -330,6 +330,36 @@ def lookahead_decode(policy, value, features, captions, beam=5, max_seq_len=17, 
             "logit_margin": logit_margin, "score_margin": score_margin}
 
 
+def policy_ce_step(policy, features, captions, dtype=torch.float64):
+    """One minibatch of train_policy_network (trainers.py:228-242): teacher-forced logits of
+    captions[:, :-1], loss = sum_i (caplen_i / N) * CrossEntropy(output[i][:caplen_i], captions[i, 1:][:caplen_i])
+    with caplen_i = index of the first <END> (2) + 1 and the slices clipped to the L-1 positions that
+    exist.  Returns (loss float, gradients dict)."""
+    P = to_t(policy, dtype, requires_grad=True)
+    caps = np.asarray(captions)
+    n, l_cols = caps.shape
+    _, _, logp = policy_rollout(P, features, caps[:, :1], l_cols - 1, mode="forced", forced=caps[:, 1:])
+    loss = 0.0
+    for i in range(n):
+        caplen = int(np.nonzero(caps[i] == 2)[0][0]) + 1
+        valid = min(caplen, l_cols - 1)
+        loss = loss + (caplen / n) * (-logp[i, :valid]).mean()
+    loss.backward()
+    return float(loss), {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}
+
+
+def value_mse_step(value, features, captions, targets, dtype=torch.float64):
+    """One minibatch of train_value_network after the greedy rollout and its reward
+    (trainers.py:175-190): ValueNetwork on captions [N, r] from a zero chain state, nn.MSELoss against
+    targets [N].  Returns (loss float, values [N], gradients dict)."""
+    Vp = to_t(value, dtype, requires_grad=True)
+    caps = np.asarray(captions)
+    values = value_forward(Vp, features, torch.as_tensor(caps, dtype=torch.int64), caps.shape[1], 1)[:, 0]
+    loss = ((values - torch.as_tensor(np.asarray(targets), dtype=dtype)) ** 2).mean()
+    loss.backward()
+    return float(loss), values.detach().numpy(), {k: v.grad.numpy() for k, v in Vp.items() if v.grad is not None}
+
+
 def adam_update(params, grads, state, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.Adam (no amsgrad, no weight decay), in place on float64 copies.
     state: dict with 'step', 'm', 'v' (created on first use)."""

@@ -11,7 +11,7 @@ empty placeholder modules are registered for those names; the tensorboard
 placeholder's SummaryWriter records the (tag, value, step) triples, which are the
 reference's per-minibatch outputs (trainers.py:489-492).
 
-Usage:  python oracle/gen_golden.py [--lookahead-only]           (writes tests/golden/)
+Usage:  python oracle/gen_golden.py [--lookahead-only | --pretrain-only]           (writes tests/golden/)
 """
 import importlib
 import os
@@ -238,6 +238,77 @@ def golden_lookahead(models, trainers, cfg):
             "logit_margin": np.float64(want["logit_margin"]), "score_margin": np.float64(want["score_margin"])}
 
 
+def _seeded_factory(models, kind, vocab, fdim, seed):
+    """A stand-in for the reference's constructor call inside its training loops: builds the
+    reference class, then overwrites its fresh parameters with the seeded recipe's."""
+    cls = {"policy": models.PolicyNetwork, "value": models.ValueNetwork, "reward": models.RewardNetwork}[kind]
+
+    def make(word_to_idx, **kw):
+        net = cls(word_to_idx, **kw)
+        params = synthetic.make_params(kind, vocab, fdim, seed)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        return net
+    return make
+
+
+def golden_pretrain(models, trainers, cfg, tmp):
+    """The reference's train_policy_network and train_value_network (trainers.py:125-257), two epochs
+    of one minibatch each on ragged seeded captions: the logged losses, parameter summaries after the
+    two updates and, for the value loop, what it fed the value network (row order, greedy captions,
+    rewards, prefix lengths)."""
+    import random
+    n, vocab, fdim, seed = cfg["n"], cfg["vocab"], cfg["fdim"], cfg["seed"]
+    data = synthetic.make_ragged_train_data(n, vocab, fdim, seed)
+    out = {"cfg": np.array([n, vocab, 17, fdim, seed])}
+    paths = {k: os.path.join(tmp, k + ".pt") for k in ("policy_network", "value_network", "reward_network")}
+    saved = (trainers.PolicyNetwork, trainers.ValueNetwork, trainers.RewardNetwork)
+    try:
+        trainers.PolicyNetwork = _seeded_factory(models, "policy", vocab, fdim, seed)
+        trainers.ValueNetwork = _seeded_factory(models, "value", vocab, fdim, seed)
+        trainers.RewardNetwork = _seeded_factory(models, "reward", vocab, fdim, seed)
+        # policy
+        del SCALARS[:]
+        torch.manual_seed(seed)
+        pol = trainers.train_policy_network(data, paths, tmp, False, epochs=2, batch_size=n)
+        out["policy_losses"] = np.array([v for tag, v, _ in SCALARS if tag == "Policy Network-loss"])
+        summarize("policy_after", dict(pol.named_parameters()), out)
+        # value: frozen policy / reward networks come from files, as the reference loads them
+        torch.save(trainers.PolicyNetwork(data["word_to_idx"]).state_dict(), paths["policy_network"])
+        torch.save(trainers.RewardNetwork(data["word_to_idx"]).state_dict(), paths["reward_network"])
+        rec = {"caps": [], "rewards": [], "cols": [], "rows": []}
+        orig_rewards, orig_randint = trainers.GetRewards, random.randint
+
+        def rewards_spy(features, captions, reward_network):
+            r = orig_rewards(features, captions, reward_network)
+            rec["caps"].append(captions.detach().numpy().copy())
+            rec["rewards"].append(r.detach().numpy()[:, 0].copy())
+            f = features.detach().numpy()   # which data rows, in which order (the chain walks them in order)
+            rec["rows"].append([int(np.nonzero((data["train_features"] == f[i]).all(axis=1))[0][0]) for i in range(n)])
+            return r
+
+        def randint_spy(a, b):
+            v = orig_randint(a, b)
+            rec["cols"].append(v)
+            return v
+        trainers.GetRewards, random.randint = rewards_spy, randint_spy
+        try:
+            del SCALARS[:]
+            torch.manual_seed(seed)
+            random.seed(seed)
+            val = trainers.train_value_network(data, paths, tmp, False, epochs=2, batch_size=n)
+        finally:
+            trainers.GetRewards, random.randint = orig_rewards, orig_randint
+        out["value_losses"] = np.array([v for tag, v, _ in SCALARS if tag == "Value Network-loss"])
+        out["value_gen_caps"] = np.stack(rec["caps"]).astype(np.int64)
+        out["value_rewards"] = np.stack(rec["rewards"])
+        out["value_cols"] = np.array(rec["cols"])
+        summarize("value_after", dict(val.named_parameters()), out)
+    finally:
+        trainers.PolicyNetwork, trainers.ValueNetwork, trainers.RewardNetwork = saved
+    out["value_rows"] = np.array(rec["rows"])
+    return out
+
+
 CONFIGS = [
     dict(name="n4_v100_l10_f512_s0", n=4, vocab=100, caplen=10, fdim=512, seed=0),
     dict(name="n4_v100_l10_f512_s1", n=4, vocab=100, caplen=10, fdim=512, seed=1),
@@ -250,6 +321,14 @@ def main():
     models, trainers = import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
+    if "--pretrain-only" in sys.argv:
+        import tempfile
+        cfg = dict(name="n6_v100_f512_s1", n=6, vocab=100, fdim=512, seed=1)
+        with tempfile.TemporaryDirectory() as tmp:
+            out = golden_pretrain(models, trainers, cfg, tmp)
+        np.savez_compressed(os.path.join(gdir, "pretrain_%s.npz" % cfg["name"]), **out)
+        print("wrote pre-training", cfg["name"], out["policy_losses"], out["value_losses"], out["value_cols"])
+        return
     for cfg in ([] if "--lookahead-only" in sys.argv else CONFIGS):
         out = golden_for(models, trainers, cfg)
         out.update(golden_greedy(models, trainers, cfg))

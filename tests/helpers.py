@@ -35,6 +35,9 @@ def load_lookahead(name):
     return g
 
 
+GOLDEN_PRETRAIN = "pretrain_n6_v100_f512_s1"
+
+
 def _hash_name(name):
     h = 0
     for ch in name:

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, check_summary, load_golden, load_lookahead,
+from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, GOLDEN_PRETRAIN, check_summary, load_golden, load_lookahead,
                      params_for, synthetic)
 from oracle import a2c_oracle as orc
 
@@ -151,6 +151,59 @@ def test_test_a2c_network_writes_the_three_files(tmp_path):
     # batches of 3 rows (rows 0-2 and 4: the reference's slice drops one row per batch), no newline between batches
     assert real.count("\n") == gen.count("\n") == urls.count("\n") == 2
     assert real.startswith("<START>") and gen.startswith("<START>") and "url" in urls
+
+
+def _seeded(cls, kind, cfg):
+    """The reference's loops construct their networks themselves; the golden run swapped its constructors
+    for ones that load the seeded parameters, and so does this."""
+    def make(word_to_idx, **kw):
+        net = cls(word_to_idx, **kw)
+        params = synthetic.make_params(kind, cfg["vocab"], cfg["fdim"], cfg["seed"])
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        return net
+    return make
+
+
+def test_pretraining_loops_match_reference(tmp_path, monkeypatch):
+    """train_policy_network and train_value_network (trainers.py:125-257), two epochs of one ragged
+    minibatch each, against the reference's own run: logged losses and the parameters after both
+    Adam(1e-3) updates."""
+    g = load_lookahead(GOLDEN_PRETRAIN)
+    cfg = g["cfg"]
+    n = cfg["n"]
+    data = synthetic.make_ragged_train_data(n, cfg["vocab"], cfg["fdim"], cfg["seed"])
+    paths = {k: str(tmp_path / (k + ".pt")) for k in ("policy_network", "value_network", "reward_network")}
+    monkeypatch.setattr(trainers, "PolicyNetwork", _seeded(models.PolicyNetwork, "policy", cfg))
+    monkeypatch.setattr(trainers, "ValueNetwork", _seeded(models.ValueNetwork, "value", cfg))
+    monkeypatch.setattr(trainers, "RewardNetwork", _seeded(models.RewardNetwork, "reward", cfg))
+    log = trainers.ScalarLog()
+    pol = trainers.train_policy_network(data, paths, log, False, epochs=2, batch_size=n)
+    losses = np.array([r[1] for r in log.records if r[0] == "Policy Network-loss"])
+    np.testing.assert_allclose(losses, g["policy_losses"], rtol=2e-4)
+    assert [r[2] for r in log.records] == [0, n]
+    for k, p in pol.named_parameters():
+        check_summary(g, "policy_after", k, p.data.cpu().numpy(), 1e-4, 3e-6)
+    saved = torch.load(paths["policy_network"], weights_only=True)   # best loss came second: saved before that update
+    assert set(saved) == set(pol.state_dict())
+
+    # the value loop: frozen networks from files; feed the rows in the order the reference's run drew them
+    torch.save(trainers.PolicyNetwork(data["word_to_idx"], input_dim=cfg["fdim"]).state_dict(), paths["policy_network"])
+    torch.save(trainers.RewardNetwork(data["word_to_idx"], feature_dim=cfg["fdim"]).state_dict(), paths["reward_network"])
+    order = iter(g["value_rows"])
+
+    def batches(d, batch_size=100, split="train"):
+        rows = next(order)
+        yield d["train_captions"][rows], d["train_features"][rows], d["train_urls"][rows]
+    monkeypatch.setattr(trainers, "minibatches", batches)
+    cols = iter(int(c) for c in g["value_cols"])
+    import random
+    monkeypatch.setattr(random, "randint", lambda a, b: next(cols))
+    log = trainers.ScalarLog()
+    val = trainers.train_value_network(data, paths, log, False, epochs=2, batch_size=n)
+    losses = np.array([r[1] for r in log.records if r[0] == "Value Network-loss"])
+    np.testing.assert_allclose(losses, g["value_losses"], rtol=5e-3, atol=1e-6)
+    for k, p in val.named_parameters():
+        check_summary(g, "value_after", k, p.data.cpu().numpy(), 1e-4, 3e-6)
 
 
 def test_a2c_training_entry_point_two_minibatches():

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, check_summary, load_golden, load_lookahead,
+from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, GOLDEN_PRETRAIN, check_summary, load_golden, load_lookahead,
                      params_for, synthetic)
 from oracle import a2c_oracle as orc
 
@@ -110,6 +110,31 @@ def test_two_step_training_matches_reference():
     params = orc.adam_update(params, grads, state)
     for k, v in params.items():
         check_summary(g, "param2", k, v, 1e-5, 2e-6)
+
+
+def test_pretraining_steps_match_reference():
+    """Two minibatches of the reference's policy and value pre-training loops (length-weighted cross
+    entropy; MSE against the greedy rollout's reward) against the float64 restatements + Adam(1e-3)."""
+    g = load_lookahead(GOLDEN_PRETRAIN)
+    cfg = g["cfg"]
+    data = synthetic.make_ragged_train_data(cfg["n"], cfg["vocab"], cfg["fdim"], cfg["seed"])
+    pol, val, _ = params_for(cfg)
+    state = {}
+    for step in range(2):   # the policy loss does not depend on the order of the rows
+        loss, grads = orc.policy_ce_step(pol, data["train_features"], data["train_captions"])
+        assert abs(loss - g["policy_losses"][step]) <= 1e-4 * abs(loss), (step, loss)
+        pol = orc.adam_update(pol, grads, state, lr=1e-3)
+    for k, v in pol.items():
+        check_summary(g, "policy_after", k, v, 1e-5, 2e-6)
+    state = {}
+    for step in range(2):
+        rows = g["value_rows"][step]
+        caps = g["value_gen_caps"][step][:, :int(g["value_cols"][step])]
+        loss, _, grads = orc.value_mse_step(val, data["train_features"][rows], caps, g["value_rewards"][step])
+        assert abs(loss - g["value_losses"][step]) <= 2e-3 * abs(loss) + 1e-6, (step, loss)
+        val = orc.adam_update(val, grads, state, lr=1e-3)
+    for k, v in val.items():
+        check_summary(g, "value_after", k, v, 1e-5, 2e-6)
 
 
 def test_curriculum_skips_short_captions():
