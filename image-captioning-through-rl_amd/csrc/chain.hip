@@ -1,5 +1,5 @@
 // Persistent batch-1 recurrent chains (value-network LSTM forward/backward, reward-network
-// GRU forward).
+// GRU forward/backward).
 //
 // The reference runs nn.LSTM / nn.GRU with (seq = N, batch = 1), so a minibatch is ONE
 // recurrence of ~10^5 dependent 512-wide steps.  Each step is a 512 x (G*512) mat-vec plus
@@ -182,7 +182,12 @@ __global__ __launch_bounds__(256) void chain_fwd_kernel(const float* __restrict_
             const float nval = 2.f * sigm(2.f * (xq + r_at_n * hb)) - 1.f;
             const float z = __shfl_xor(a, 8, 64);                  // slot 0 receives z
             const float nn = __shfl_xor(nval, 16, 64);             // slot 0 receives n
+            const float hn = __shfl_xor(hb, 16, 64);               // slot 0 receives W_hn.h + b_hn
             h_new = (1.f - z) * nn + z * h_state;
+            if (saved && q == 0 && cq < 5) {
+                const float sv = cq == 0 ? a : cq == 1 ? z : cq == 2 ? nn : cq == 3 ? hn : h_new;
+                saved[pos * (5 * H) + cq * H + u] = sv;
+            }
         }
         h_state = h_new;
         if (q == 0 && cq == 0) {
@@ -302,6 +307,111 @@ __global__ __launch_bounds__(256) void lstm_chain_bwd_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------ GRU backward
+// Walks positions in reverse (BPTT of models.py:226 for the reward pre-training loop).  Workgroup b
+// owns units [8b, 8b+8): 32 lanes per unit, lane j holds W_hh[rho, u] for the 48 gate rows
+// rho = 4*(k*32 + j) + m of the 1536.  Per step: dh = z-path carry + sum_rho W_hh[rho, u] * dgh[rho]
+// (the gathered hidden-side gate gradients of the position above) + the injected gradient; then the
+// cell backward for its units, which publishes the unit's three hidden-side gate gradients.
+// saved[pos] = {r, z, n, hn = W_hn.h_prev + b_hn, h}; the forward pass started from a zero state.
+// dgx[pos] = gradient w.r.t. the input-side pre-activations (r, z, n), dgh[pos] = w.r.t. the
+// hidden-side ones (r, z, hn): they differ in the n slot because n = tanh(x_n + r * hn).
+__global__ __launch_bounds__(256) void gru_chain_bwd_kernel(const float* __restrict__ w_hh,
+                                                            const float* __restrict__ saved,
+                                                            const float* __restrict__ d_emit, int n, int p0x,
+                                                            int n_calls, int64_t total, float* __restrict__ dgx,
+                                                            float* __restrict__ dgh, u64* gran, int* status) {
+    __shared__ __attribute__((aligned(16))) float dgb[2][3 * H];
+    __shared__ int abort_flag;
+    const int tid = threadIdx.x;
+    const int j = tid & 31;
+    const int lu = tid >> 5;
+    const int u = blockIdx.x * UPW + lu;
+    if (tid == 0) abort_flag = 0;
+
+    float4 w[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int rho = 4 * (k * 32 + j);
+        w[k].x = w_hh[(int64_t)(rho + 0) * H + u];
+        w[k].y = w_hh[(int64_t)(rho + 1) * H + u];
+        w[k].z = w_hh[(int64_t)(rho + 2) * H + u];
+        w[k].w = w_hh[(int64_t)(rho + 3) * H + u];
+    }
+
+    PosIter it;
+    it.last(n, p0x, n_calls);
+    float carry = 0.f;   // dh * z of the position above
+    const float* sp = saved + (total - 1) * (5 * H) + u;
+    float gr = sp[0], gz = sp[H], gn = sp[2 * H], ghn = sp[3 * H];
+    float de = it.emits() ? d_emit[it.emit_row() * H + u] : 0.f;
+    __syncthreads();
+
+    for (int64_t k = 0; k < total; ++k) {
+        const int64_t pos = total - 1 - k;
+        const unsigned par = (unsigned)k & 1u;
+        // prefetch position pos-1: its h is this position's h_prev
+        PosIter pv = it;
+        float nr = 0.f, nz = 0.f, nnv = 0.f, nhn = 0.f, hprev = 0.f, nde = 0.f;
+        if (pos > 0) {
+            pv.prev();
+            const float* sn = saved + (pos - 1) * (5 * H) + u;
+            nr = sn[0]; nz = sn[H]; nnv = sn[2 * H]; nhn = sn[3 * H]; hprev = sn[4 * H];
+            if (pv.emits()) nde = d_emit[pv.emit_row() * H + u];
+        }
+
+        float dh = 0.f;
+        if (k > 0) {
+            float dv[6];
+            const bool ok = poll_granules<6>(gran + (par ^ 1u) * GRAN_PER_SET + 6 * tid, (unsigned)k, dv);
+            if (!ok) abort_flag = 1;
+            float2* dst = reinterpret_cast<float2*>(&dgb[par][6 * tid]);
+            dst[0] = make_float2(dv[0], dv[1]);
+            dst[1] = make_float2(dv[2], dv[3]);
+            dst[2] = make_float2(dv[4], dv[5]);
+            __syncthreads();
+            if (abort_flag) {
+                if (tid == 0) atomicExch(status, 3);
+                return;
+            }
+            const float4* d4 = reinterpret_cast<const float4*>(dgb[par]);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk) {
+                const float4 d = d4[kk * 32 + j];
+                a0 = fmaf(w[kk].x, d.x, a0);
+                a1 = fmaf(w[kk].y, d.y, a1);
+                a2 = fmaf(w[kk].z, d.z, a2);
+                a3 = fmaf(w[kk].w, d.w, a3);
+            }
+            dh = (a0 + a1) + (a2 + a3);
+            dh += __shfl_xor(dh, 1, 64);
+            dh += __shfl_xor(dh, 2, 64);
+            dh += __shfl_xor(dh, 4, 64);
+            dh += __shfl_xor(dh, 8, 64);
+            dh += __shfl_xor(dh, 16, 64);
+        }
+        dh += carry + de;
+
+        // cell backward for unit u (identical in the unit's 32 lanes)
+        const float dn_pre = dh * (1.f - gz) * (1.f - gn * gn);
+        const float dz_pre = dh * (hprev - gn) * gz * (1.f - gz);
+        const float dr_pre = dn_pre * ghn * gr * (1.f - gr);
+        const float d_hn = dn_pre * gr;
+        carry = dh * gz;
+        if (j < 3) {
+            const float qx = j == 0 ? dr_pre : j == 1 ? dz_pre : dn_pre;
+            const float qh = j == 0 ? dr_pre : j == 1 ? dz_pre : d_hn;
+            dgx[pos * (3 * H) + j * H + u] = qx;
+            dgh[pos * (3 * H) + j * H + u] = qh;
+            if (pos > 0)
+                __hip_atomic_store(gran + par * GRAN_PER_SET + j * H + u, pack((unsigned)k + 1u, qh), RLX, AGENT);
+        }
+        gr = nr; gz = nz; gn = nnv; ghn = nhn; de = nde;
+        it = pv;
+    }
+}
+
 int chain_args_ok(const char* who, int N, int p0, int n_calls) {
     if (N <= 0 || p0 <= 0 || n_calls <= 0) {
         set_error("%s: N, p0 and n_calls must be positive (got %d, %d, %d)", who, N, p0, n_calls);
@@ -338,8 +448,8 @@ extern "C" int icrl_lstm_chain_fwd(const float* xproj, const float* w_hh, int N,
 }
 
 extern "C" int icrl_gru_chain_fwd(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                  int n_calls, float* h_emit, const float* state_in, float* state_out,
-                                  void* sync_ws, int32_t* status, icrl_stream_t stream) {
+                                  int n_calls, float* h_emit, float* saved, const float* state_in,
+                                  float* state_out, void* sync_ws, int32_t* status, icrl_stream_t stream) {
     if (!chain_args_ok("icrl_gru_chain_fwd", N, p0, n_calls)) return ICRL_ERR_ARG;
     ICRL_REQUIRE(xproj && w_hh && b_hh && h_emit && sync_ws && status, "icrl_gru_chain_fwd: null pointer");
     ICRL_REQUIRE(reinterpret_cast<uintptr_t>(w_hh) % 16 == 0 && reinterpret_cast<uintptr_t>(sync_ws) % 16 == 0,
@@ -348,7 +458,7 @@ extern "C" int icrl_gru_chain_fwd(const float* xproj, const float* w_hh, const f
     ICRL_HIP(hipMemsetAsync(sync_ws, 0, SYNC_BYTES, st));
     ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(chain_fwd_kernel<true>, dim3(WGS), dim3(256), 0, st, xproj, w_hh, b_hh, N, p0, n_calls,
-                       chain_len(N, p0, n_calls), h_emit, (float*)nullptr, state_in, state_out,
+                       chain_len(N, p0, n_calls), h_emit, saved, state_in, state_out,
                        reinterpret_cast<u64*>(sync_ws), reinterpret_cast<int*>(status));
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
@@ -365,6 +475,23 @@ extern "C" int icrl_lstm_chain_bwd(const float* w_hh, const float* saved, const 
     ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(lstm_chain_bwd_kernel, dim3(WGS), dim3(256), 0, st, w_hh, saved, d_emit, N, p0, n_calls,
                        chain_len(N, p0, n_calls), dgates, reinterpret_cast<u64*>(sync_ws),
+                       reinterpret_cast<int*>(status));
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_gru_chain_bwd(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                                  int n_calls, float* dgates_x, float* dgates_h, void* sync_ws, int32_t* status,
+                                  icrl_stream_t stream) {
+    if (!chain_args_ok("icrl_gru_chain_bwd", N, p0, n_calls)) return ICRL_ERR_ARG;
+    ICRL_REQUIRE(w_hh && saved && d_emit && dgates_x && dgates_h && sync_ws && status,
+                 "icrl_gru_chain_bwd: null pointer");
+    ICRL_REQUIRE(reinterpret_cast<uintptr_t>(sync_ws) % 16 == 0, "icrl_gru_chain_bwd: sync_ws must be 16-byte aligned");
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(sync_ws, 0, SYNC_BYTES, st));
+    ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(gru_chain_bwd_kernel, dim3(WGS), dim3(256), 0, st, w_hh, saved, d_emit, N, p0, n_calls,
+                       chain_len(N, p0, n_calls), dgates_x, dgates_h, reinterpret_cast<u64*>(sync_ws),
                        reinterpret_cast<int*>(status));
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;

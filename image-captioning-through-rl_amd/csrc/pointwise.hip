@@ -245,6 +245,55 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------- visual-semantic embedding loss
+// VisualSemanticEmbeddingLoss (trainers.py:21-54) from S = visuals . semantics^T [N, N], margin = beta / N:
+//   loss = (sum_ij relu(S_ij - S_ii + m_ij) + sum_ij relu(S_ji - S_ii + m_ij)) / N,  m_ij = margin * (i != j).
+// One workgroup per row i: the row's share of the loss and row i of dLoss/dS,
+//   dS_ij = ([S_ij - S_ii + m > 0] + [S_ij - S_jj + m > 0]) / N                  (i != j)
+//   dS_ii = -(sum_j [S_ij - S_ii + m > 0] + sum_j [S_ji - S_ii + m > 0]) / N     (j != i)
+__global__ __launch_bounds__(256) void vse_rows_kernel(const float* __restrict__ S, int n, float margin,
+                                                       float* __restrict__ row_loss, float* __restrict__ dS) {
+    __shared__ double redl[4];
+    __shared__ float redc[4];
+    const int i = blockIdx.x;
+    const float sii = S[(int64_t)i * n + i];
+    const float inv = 1.0f / (float)n;
+    double loss = 0.;
+    float cnt = 0.f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        if (j == i) continue;
+        const float sij = S[(int64_t)i * n + j], sji = S[(int64_t)j * n + i], sjj = S[(int64_t)j * n + j];
+        const float a = sij - sii + margin;     // image i against caption j
+        const float b = sji - sii + margin;     // caption i against image j
+        const float a2 = sij - sjj + margin;    // caption j against image i (its term lives in row j's sum)
+        loss += (double)fmaxf(a, 0.f) + (double)fmaxf(b, 0.f);
+        cnt += (a > 0.f ? 1.f : 0.f) + (b > 0.f ? 1.f : 0.f);
+        if (dS) dS[(int64_t)i * n + j] = ((a > 0.f ? 1.f : 0.f) + (a2 > 0.f ? 1.f : 0.f)) * inv;
+    }
+    loss = wave_sum_d(loss);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { redl[threadIdx.x >> 6] = loss; redc[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        row_loss[i] = (float)((redl[0] + redl[1]) + (redl[2] + redl[3]));
+        if (dS) dS[(int64_t)i * n + i] = -((redc[0] + redc[1]) + (redc[2] + redc[3])) * inv;
+    }
+}
+
+__global__ __launch_bounds__(1024) void vse_sum_kernel(const float* __restrict__ row_loss, int n, float* __restrict__ loss) {
+    __shared__ double red[16];
+    double acc = 0.;
+    for (int e = threadIdx.x; e < n; e += 1024) acc += (double)row_loss[e];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.;
+        for (int w = 0; w < 16; ++w) a += red[w];
+        loss[0] = (float)(a / n);
+    }
+}
+
 // g[r,k] = coef[r] * (onehot(token[r])[k] - p[r,k]); g may alias p
 __global__ __launch_bounds__(256) void policy_dlogits_kernel(const float* p, float* g, int rows, int V,
                                                              const int64_t* __restrict__ tokens,
@@ -317,15 +366,15 @@ __global__ __launch_bounds__(256) void chain_fold_kernel(const float* __restrict
     }
 }
 
-// h_prev[pos,:] = saved[pos-1, 5H:6H] (zeros at pos 0)
+// h_prev[pos,:] = saved[pos-1, h_slot] (zeros at pos 0); `slots` x 512 floats per position
 __global__ __launch_bounds__(256) void chain_hprev_kernel(const float* __restrict__ saved, int64_t positions,
-                                                          float4* __restrict__ h_prev) {
+                                                          int slots, int h_slot, float4* __restrict__ h_prev) {
     const int64_t total = positions * (H / 4);
     for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t pos = e / (H / 4);
         const int c = (int)(e % (H / 4));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pos > 0) v = reinterpret_cast<const float4*>(saved + (pos - 1) * 6 * H + 5 * H)[c];
+        if (pos > 0) v = reinterpret_cast<const float4*>(saved + ((pos - 1) * slots + h_slot) * H)[c];
         h_prev[e] = v;
     }
 }
@@ -448,6 +497,15 @@ extern "C" int icrl_mse_loss(const float* values, const float* targets, int coun
     return ICRL_OK;
 }
 
+extern "C" int icrl_vse_loss(const float* S, int N, float beta, float* row_scratch, float* loss, float* dS,
+                             icrl_stream_t stream) {
+    ICRL_REQUIRE(S && row_scratch && loss && N > 0, "icrl_vse_loss: null pointer or N <= 0");
+    hipLaunchKernelGGL(vse_rows_kernel, dim3(N), dim3(256), 0, as_stream(stream), S, N, beta / (float)N, row_scratch, dS);
+    hipLaunchKernelGGL(vse_sum_kernel, dim3(1), dim3(1024), 0, as_stream(stream), row_scratch, N, loss);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
 extern "C" int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, const int64_t* tokens,
                                    int64_t token_stride, const float* coef, icrl_stream_t stream) {
     ICRL_REQUIRE(probs && dlogits && tokens && coef && rows > 0 && V > 0,
@@ -482,10 +540,12 @@ extern "C" int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_c
     return ICRL_OK;
 }
 
-extern "C" int icrl_chain_hprev(const float* saved, int64_t positions, float* h_prev, icrl_stream_t stream) {
+extern "C" int icrl_chain_hprev(const float* saved, int64_t positions, int gru, float* h_prev,
+                                icrl_stream_t stream) {
     ICRL_REQUIRE(saved && h_prev && positions > 0, "icrl_chain_hprev: bad argument");
     hipLaunchKernelGGL(chain_hprev_kernel, dim3(grid_for(positions * (H / 4), 256)), dim3(256), 0,
-                       as_stream(stream), saved, positions, reinterpret_cast<float4*>(h_prev));
+                       as_stream(stream), saved, positions, gru ? 5 : 6, gru ? 4 : 5,
+                       reinterpret_cast<float4*>(h_prev));
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -57,13 +57,14 @@ class A2CEngine:
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
 
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
+                 reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
         missing from the grads dicts (e.g. frozen pretrained embeddings) get no gradient."""
         self.P, self.V, self.R = policy_params, value_params, reward_params
-        self.gP, self.gV = policy_grads or {}, value_grads or {}
+        self.gP, self.gV, self.gR = policy_grads or {}, value_grads or {}, reward_grads or {}
         self.concurrent = concurrent
         self.want_entropy = entropy  # per-(step,row) policy entropy: a diagnostic, not part of the loss
         self.persistent = persistent  # persistent chain kernels (one launch for all steps) when the device can hold them
@@ -268,6 +269,67 @@ class A2CEngine:
         hip.chain_hprev(ws["saved"], ws["tv"], ws["hprev"])
         self._value_chain_backward(ws, n, p0, 1, main, main, ("exact",), None)
         return ws["scalars"][0:1], ws["values"]
+
+    def reward_vse_step(self, features, captions, beta=0.2):
+        """One minibatch of the reward pre-training loop (trainers.py:286-300): the GRU chain over the
+        whole captions [N, L] (walked exactly, activations kept), the two embeddings,
+        VisualSemanticEmbeddingLoss on their [N, N] similarity matrix, and the gradients of every reward
+        network parameter (BPTT through the batch-1 chain included).  Returns the loss (1-element tensor)."""
+        R, gR = self.R, self.gR
+        n, l_cols = captions.shape
+        key = ("vse", n, l_cols)
+        ws = self._ws.get(key)
+        dev = self.device
+        er = R["rewrnn.caption_embedding.weight"].shape[1]
+        pos = n * l_cols
+        if ws is None:
+            def f32(*shape):
+                return torch.empty(*shape, dtype=torch.float32, device=dev)
+            ws = dict(tok=torch.zeros(l_cols, n, dtype=torch.int64, device=dev), X=f32(pos, er), XP=f32(pos, 3 * H),
+                      hr=f32(1, n, H), saved=f32(pos, 5, H), se=f32(n, 512), ve=f32(n, 512), S=f32(n, n), dS=f32(n, n),
+                      rows=f32(n), loss=torch.zeros(1, dtype=torch.float32, device=dev), dse=f32(n, 512),
+                      dve=f32(n, 512), d_emit=f32(1, n, H), dgx=f32(pos, 3 * H), dgh=f32(pos, 3 * H), hprev=f32(pos, H),
+                      dX=f32(pos, er), scratch=f32(max(16 * 3 * H * H, 16 * 512 * max(512, self.F))),
+                      sync=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
+                      status=torch.zeros(4, dtype=torch.int32, device=dev))
+            self._ws[key] = ws
+        ws["tok"].copy_(captions.t())
+        tok = ws["tok"].view(-1)
+        w_ih, w_hh = R["rewrnn.gru.weight_ih_l0"], R["rewrnn.gru.weight_hh_l0"]
+        # ---- forward
+        hip.gather_rows(R["rewrnn.caption_embedding.weight"], tok, 1, pos, ws["X"])
+        hip.gemm(ws["X"], w_ih, ws["XP"], bias=R["rewrnn.gru.bias_ih_l0"])
+        hip.gru_chain_fwd(ws["XP"], w_hh, R["rewrnn.gru.bias_hh_l0"], n, l_cols, 1, ws["hr"], ws["sync"],
+                          ws["status"][0:1], saved=ws["saved"])
+        hr = ws["hr"].view(n, H)
+        hip.gemm(hr, R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
+        hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+        hip.gemm(ws["ve"], ws["se"], ws["S"])                                  # S = ve . se^T
+        hip.vse_loss(ws["S"], beta, ws["rows"], ws["loss"], ws["dS"])
+        # ---- backward: the two linear layers
+        sc = ws["scratch"]
+        hip.gemm(ws["dS"], ws["se"], ws["dve"], b_kmajor=True)                 # dve = dS . se
+        hip.gemm(ws["dS"], ws["ve"], ws["dse"], a_kmajor=True, b_kmajor=True)  # dse = dS^T . ve
+        hip.gemm_auto(ws["dve"], features, gR["visual_embed.weight"], sc, a_kmajor=True, b_kmajor=True)
+        hip.colsum(ws["dve"], gR["visual_embed.bias"])
+        hip.gemm_auto(ws["dse"], hr, gR["semantic_embed.weight"], sc, a_kmajor=True, b_kmajor=True)
+        hip.colsum(ws["dse"], gR["semantic_embed.bias"])
+        hip.gemm(ws["dse"], R["semantic_embed.weight"], ws["d_emit"].view(n, H), b_kmajor=True)
+        # ---- backward: the chain, then its weight gradients as products over all positions
+        hip.gru_chain_bwd(w_hh, ws["saved"], ws["d_emit"], n, l_cols, 1, ws["dgx"], ws["dgh"], ws["sync"],
+                          ws["status"][1:2])
+        hip.chain_hprev(ws["saved"], pos, ws["hprev"], gru=True)
+        hip.gemm_auto(ws["dgh"], ws["hprev"], gR["rewrnn.gru.weight_hh_l0"], sc, a_kmajor=True, b_kmajor=True)
+        hip.colsum(ws["dgh"], gR["rewrnn.gru.bias_hh_l0"])
+        hip.gemm_auto(ws["dgx"], ws["X"], gR["rewrnn.gru.weight_ih_l0"], sc, a_kmajor=True, b_kmajor=True)
+        hip.colsum(ws["dgx"], gR["rewrnn.gru.bias_ih_l0"])
+        g_emb = gR.get("rewrnn.caption_embedding.weight")
+        if g_emb is not None:
+            hip.gemm_auto(ws["dgx"], w_ih, ws["dX"], sc, b_kmajor=True)
+            g_emb.zero_()
+            hip.scatter_add_rows(g_emb, tok, 1, pos, ws["dX"])
+        self._vse_status = ws["status"]
+        return ws["loss"]
 
     # ------------------------------------------------------------------ the step
     def step(self, features, prefix, n_steps, uniforms=None, forced_tokens=None, mode=hip.SAMPLE, backward=True):

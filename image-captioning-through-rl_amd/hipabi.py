@@ -46,10 +46,12 @@ SIGNATURES = {
     "icrl_policy_dlogits": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "icrl_chain_sync_bytes": (c_i64, []),
     "icrl_lstm_chain_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_gru_chain_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_vse_loss": (c_int, [c_vp, c_int, ctypes.c_float, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_fold_calls": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
-    "icrl_chain_hprev": (c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "icrl_chain_hprev": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_value_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_cosine_reward": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_a2c_loss": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -250,12 +252,27 @@ def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, 
     _check(rc, "icrl_lstm_chain_fwd")
 
 
-def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, state_in=None, state_out=None):
+def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, state_in=None, state_out=None,
+                  saved=None):
     with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_gru_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
-                                       _ptr(_f32c(h_emit)), _ptr(state_in), _ptr(state_out), _ptr(sync_ws),
-                                       _ptr(status), _stream())
+                                       _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(state_out),
+                                       _ptr(sync_ws), _ptr(status), _stream())
     _check(rc, "icrl_gru_chain_fwd")
+
+
+def gru_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates_x, dgates_h, sync_ws, status):
+    _check(load().icrl_gru_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
+                                     _ptr(_f32c(dgates_x)), _ptr(_f32c(dgates_h)), _ptr(sync_ws), _ptr(status),
+                                     _stream()), "icrl_gru_chain_bwd")
+
+
+def vse_loss(s_matrix, beta, row_scratch, loss, d_s=None):
+    """s_matrix [N, N] = visuals @ semantics^T; loss: 1-element view; d_s: optional [N, N]."""
+    n = s_matrix.shape[0]
+    assert s_matrix.shape == (n, n) and s_matrix.is_contiguous()
+    _check(load().icrl_vse_loss(_ptr(_f32c(s_matrix)), n, float(beta), _ptr(row_scratch), _ptr(loss), _ptr(d_s),
+                                _stream()), "icrl_vse_loss")
 
 
 def lstm_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates, sync_ws, status):
@@ -270,8 +287,8 @@ def chain_fold_calls(dgates, n, p0, n_calls, width, out):
            "icrl_chain_fold_calls")
 
 
-def chain_hprev(saved, positions, h_prev):
-    _check(load().icrl_chain_hprev(_ptr(_f32c(saved)), positions, _ptr(_f32c(h_prev)), _stream()),
+def chain_hprev(saved, positions, h_prev, gru=False):
+    _check(load().icrl_chain_hprev(_ptr(_f32c(saved)), positions, int(gru), _ptr(_f32c(h_prev)), _stream()),
            "icrl_chain_hprev")
 
 

@@ -337,6 +337,35 @@ def train_value_network(train_data, network_paths, plot_dir, bidirectional, epoc
     return value_network
 
 
+def train_reward_network(train_data, network_paths, plot_dir, bidirectional, epochs=50, batch_size=512):
+    """Supervised pre-training of the reward network (trainers.py:260-309): caption and image are
+    embedded into one space and trained with VisualSemanticEmbeddingLoss (trainers.py:21-54),
+    Adam(lr=1e-4); saved whenever a minibatch improves on the best loss."""
+    fdim = int(np.asarray(train_data["train_features"]).shape[1])
+    reward_network = RewardNetwork(train_data["word_to_idx"], pretrained_embeddings=train_data["embeddings"],
+                                   bidirectional=bidirectional, feature_dim=fdim).to(device)
+    flat = flatten_module(reward_network)
+    optimizer = FusedAdam(flat, lr=0.0001)
+    engine = A2CEngine(None, None, _params_of(reward_network), reward_grads=_grads_of(reward_network))
+    writer = make_writer(plot_dir)
+    best_loss = float('inf')
+    print_green('[Training] Training Reward Network')
+    for epoch in range(epochs):
+        for minibatch_id, (captions, features, _) in enumerate(
+                minibatches(train_data, batch_size=batch_size, split='train')):
+            caps = torch.as_tensor(np.asarray(captions), device=device).long().contiguous()
+            feats = torch.as_tensor(features, device=device).float().contiguous()
+            loss = engine.reward_vse_step(feats, caps).item()
+            if int(engine._vse_status.abs().sum()) != 0:
+                raise RuntimeError("a persistent chain kernel timed out")
+            best_loss = _save_if_best(loss, best_loss, reward_network, network_paths["reward_network"])
+            writer.add_scalar('Reward Network-loss', loss, global_minibatch_number(epoch, minibatch_id, batch_size))
+            ddp.average_gradients(flat.flat_grad)
+            optimizer.step()
+            reward_network.rewrnn.init_hidden()
+    return reward_network
+
+
 def _load_or_fail(net, path, what):
     try:
         net.load_state_dict(torch.load(path, map_location=device, weights_only=True), strict=False)

@@ -144,7 +144,7 @@ int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, con
  * granules in `sync_ws` (icrl_chain_sync_bytes(), zeroed by the call itself).
  * h_emit[s, i, :] receives the hidden output at the last column of call s.
  * For the LSTM, `saved` (optional) receives per position {i,f,g,o,c,h} = 6*H floats
- * for the backward pass.  state_in (optional, {h, c} = 2*H floats, GRU: h only) is the
+ * for the backward pass; for the GRU {r, z, n, W_hn.h_prev + b_hn, h} = 5*H floats.  state_in (optional, {h, c} = 2*H floats, GRU: h only) is the
  * carried hidden state (models.py:127-128, 133: hidden_cell survives across forward()
  * calls until init_hidden()); null = zeros.  state_out (optional) receives the final
  * state.  status: one int32 the kernel sets non-zero on time-out. */
@@ -154,7 +154,7 @@ int icrl_lstm_chain_fwd(const float* xproj, const float* w_hh, int N, int p0, in
                         float* h_emit, float* saved, const float* state_in, float* state_out,
                         void* sync_ws, int32_t* status, icrl_stream_t stream);
 int icrl_gru_chain_fwd(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                       int n_calls, float* h_emit, const float* state_in, float* state_out,
+                       int n_calls, float* h_emit, float* saved, const float* state_in, float* state_out,
                        void* sync_ws, int32_t* status, icrl_stream_t stream);
 /* Backward of icrl_lstm_chain_fwd (autograd through models.py:133, trainers.py:479):
  * walks the positions in reverse; d_emit[s,i,:] is dLoss/dh_emit; writes
@@ -164,6 +164,13 @@ int icrl_gru_chain_fwd(const float* xproj, const float* w_hh, const float* b_hh,
 int icrl_lstm_chain_bwd(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
                         int n_calls, float* dgates, void* sync_ws, int32_t* status,
                         icrl_stream_t stream);
+/* Backward of icrl_gru_chain_fwd (autograd through models.py:226 in the reward pre-training loop,
+ * trainers.py:288-300): dgates_x[pos, 3H] = gradient w.r.t. the input-side pre-activations (r, z, n),
+ * dgates_h[pos, 3H] = w.r.t. the hidden-side ones (they differ in the n slot: n = tanh(x_n + r * h_n)).
+ * The forward pass must have started from a zero state. */
+int icrl_gru_chain_bwd(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                       int n_calls, float* dgates_x, float* dgates_h, void* sync_ws, int32_t* status,
+                       icrl_stream_t stream);
 /* ---- the same chains, segment-parallel with a seam check ------------------------
  * A gated recurrence forgets its initial state, so the chain is cut into `segments`
  * pieces that run side by side: each piece first runs `warmup` extra steps over the
@@ -215,8 +222,9 @@ int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const
 /* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
 int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
                           icrl_stream_t stream);
-/* h_prev[pos, :] = h of position pos-1 (zeros for pos 0), taken from `saved` */
-int icrl_chain_hprev(const float* saved, int64_t positions, float* h_prev, icrl_stream_t stream);
+/* h_prev[pos, :] = h of position pos-1 (zeros for pos 0), taken from `saved` (gru = 0: the LSTM
+ * chain's 6 slots per position; 1: the GRU chain's 5) */
+int icrl_chain_hprev(const float* saved, int64_t positions, int gru, float* h_prev, icrl_stream_t stream);
 
 /* ---- value head (models.py:175-178) ------------------------------------------
  * y[r,:] = yh[r,:] + u[r % N,:]  (u = W1[:, :F]*feat + b1, yh = W1[:, F:]*h_emit);
@@ -236,6 +244,12 @@ int icrl_cosine_reward(const float* ve, const float* se, int rows, int N, float*
  * dLoss/dlog_prob (the advantage is not detached in the reference). */
 int icrl_a2c_loss(const float* values, const float* rewards, const float* log_probs, int count,
                   float* scalars, float* d_value, float* d_logp, icrl_stream_t stream);
+
+/* VisualSemanticEmbeddingLoss (trainers.py:21-54) from S = visuals . semantics^T [N, N]:
+ * loss[0] = (sum_ij relu(S_ij - S_ii + m_ij) + sum_ij relu(S_ji - S_ii + m_ij)) / N with
+ * m_ij = (beta / N) * (i != j); dS (optional) = dLoss/dS.  row_scratch: N floats. */
+int icrl_vse_loss(const float* S, int N, float beta, float* row_scratch, float* loss, float* dS,
+                  icrl_stream_t stream);
 
 /* Length-weighted teacher-forced cross entropy of the policy pre-training loop
  * (trainers.py:238-242): loss[0] = sum_i row_weight[i] * sum_{t < valid_steps[i]} -log_probs[t*N+i];

@@ -360,6 +360,41 @@ def value_mse_step(value, features, captions, targets, dtype=torch.float64):
     return float(loss), values.detach().numpy(), {k: v.grad.numpy() for k, v in Vp.items() if v.grad is not None}
 
 
+def vse_loss(visuals, semantics, beta=0.2):
+    """VisualSemanticEmbeddingLoss, trainers.py:21-54."""
+    n = visuals.shape[0]
+    margin = (beta / n) * (torch.ones(n, n, dtype=visuals.dtype) - torch.eye(n, dtype=visuals.dtype))
+    vis = visuals @ semantics.t()
+    vis = torch.relu(vis - torch.diag(vis).unsqueeze(1) + margin).sum() / n
+    sem = semantics @ visuals.t()
+    sem = torch.relu(sem - torch.diag(sem).unsqueeze(1) + margin).sum() / n
+    return vis + sem
+
+
+def reward_vse_step(reward, features, captions, dtype=torch.float64):
+    """One minibatch of train_reward_network (trainers.py:286-300): RewardNetwork on the whole captions
+    [N, L] from a zero chain state (one batch-1 GRU recurrence over columns, then rows), the VSE loss of
+    the un-normalised embeddings.  Returns (loss float, gradients dict)."""
+    Rp = to_t(reward, dtype, requires_grad=True)
+    caps = torch.as_tensor(np.asarray(captions), dtype=torch.int64)
+    n, l_cols = caps.shape
+    feats = torch.as_tensor(features, dtype=dtype)
+    xp = Rp["rewrnn.caption_embedding.weight"][caps] @ Rp["rewrnn.gru.weight_ih_l0"].t() + Rp["rewrnn.gru.bias_ih_l0"]
+    whh_t, bhh = Rp["rewrnn.gru.weight_hh_l0"].t(), Rp["rewrnn.gru.bias_hh_l0"]
+    h = torch.zeros(1, H, dtype=dtype)
+    outs = None
+    for t in range(l_cols):
+        outs = []
+        for i in range(n):
+            h = _gru_step(xp[i, t][None], h, whh_t, bhh)
+            outs.append(h[0])
+    se = torch.stack(outs, 0) @ Rp["semantic_embed.weight"].t() + Rp["semantic_embed.bias"]
+    ve = feats @ Rp["visual_embed.weight"].t() + Rp["visual_embed.bias"]
+    loss = vse_loss(ve, se)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in Rp.items() if v.grad is not None}
+
+
 def adam_update(params, grads, state, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.Adam (no amsgrad, no weight decay), in place on float64 copies.
     state: dict with 'step', 'm', 'v' (created on first use)."""

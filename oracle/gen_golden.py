@@ -306,6 +306,25 @@ def golden_pretrain(models, trainers, cfg, tmp):
     finally:
         trainers.PolicyNetwork, trainers.ValueNetwork, trainers.RewardNetwork = saved
     out["value_rows"] = np.array(rec["rows"])
+    # reward: the row order matters here too (one GRU recurrence over the rows of a minibatch)
+    saved = (trainers.RewardNetwork, trainers.get_coco_minibatches)
+    rows = []
+
+    def batches_spy(d, batch_size=100, split="train"):
+        for caps, feats, urls in saved[1](d, batch_size=batch_size, split=split):
+            rows.append([int(np.nonzero((d["train_features"] == feats[i]).all(axis=1))[0][0]) for i in range(len(feats))])
+            yield caps, feats, urls
+    try:
+        trainers.RewardNetwork = _seeded_factory(models, "reward", vocab, fdim, seed)
+        trainers.get_coco_minibatches = batches_spy
+        del SCALARS[:]
+        torch.manual_seed(seed)
+        rew = trainers.train_reward_network(data, paths, tmp, False, epochs=2, batch_size=n)
+    finally:
+        trainers.RewardNetwork, trainers.get_coco_minibatches = saved
+    out["reward_losses"] = np.array([v for tag, v, _ in SCALARS if tag == "Reward Network-loss"])
+    out["reward_rows"] = np.array(rows)
+    summarize("reward_after", dict(rew.named_parameters()), out)
     return out
 
 
@@ -327,7 +346,8 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             out = golden_pretrain(models, trainers, cfg, tmp)
         np.savez_compressed(os.path.join(gdir, "pretrain_%s.npz" % cfg["name"]), **out)
-        print("wrote pre-training", cfg["name"], out["policy_losses"], out["value_losses"], out["value_cols"])
+        print("wrote pre-training", cfg["name"], out["policy_losses"], out["value_losses"], out["value_cols"],
+              out["reward_losses"])
         return
     for cfg in ([] if "--lookahead-only" in sys.argv else CONFIGS):
         out = golden_for(models, trainers, cfg)

@@ -205,6 +205,15 @@ def test_pretraining_loops_match_reference(tmp_path, monkeypatch):
     for k, p in val.named_parameters():
         check_summary(g, "value_after", k, p.data.cpu().numpy(), 1e-4, 3e-6)
 
+    # the reward loop: VSE loss, BPTT through the GRU chain; rows in the reference run's order
+    order = iter(g["reward_rows"])
+    log = trainers.ScalarLog()
+    rew = trainers.train_reward_network(data, paths, log, False, epochs=2, batch_size=n)
+    losses = np.array([r[1] for r in log.records if r[0] == "Reward Network-loss"])
+    np.testing.assert_allclose(losses, g["reward_losses"], rtol=2e-3)
+    for k, p in rew.named_parameters():
+        check_summary(g, "reward_after", k, p.data.cpu().numpy(), 1e-4, 3e-6)
+
 
 def test_a2c_training_entry_point_two_minibatches():
     """trainers.a2c_training driven exactly as the golden generator drove the reference:

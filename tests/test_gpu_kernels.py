@@ -433,3 +433,60 @@ def test_topk_rows_matches_torch(n, v, k):
     x[:, 7] = x[:, 3] = 100.0
     vals, idx = hip.topk_rows(x, min(k, 2))
     assert idx[:, 0].tolist() == [3] * n and (k == 1 or idx[:, 1].tolist() == [7] * n)
+
+
+# --------------------------------------------------------------------------- reward pre-training kernels
+def test_gru_chain_backward_and_vse_loss_match_autograd():
+    """GRU chain forward (activations kept) + backward against float64 autograd of the same batch-1
+    recurrence, and the visual-semantic embedding loss with its gradient against the formula."""
+    rs = np.random.RandomState(21)
+    n, p0, calls = 5, 3, 1
+    cols = p0
+    xproj, w_hh = _chain_inputs(rs, n, cols, 3)
+    b_hh = rnd(rs, 3 * H, scale=0.1)
+    d_emit = rnd(rs, calls, n, H)
+    pos = n * cols
+    xd, wd, bd = dev(xproj), dev(w_hh), dev(b_hh)
+    ws, status = _ws()
+    h_emit, saved = torch.zeros(calls, n, H, device="cuda"), torch.zeros(pos, 5, H, device="cuda")
+    dgx, dgh = torch.zeros(pos, 3 * H, device="cuda"), torch.zeros(pos, 3 * H, device="cuda")
+    hip.gru_chain_fwd(xd, wd, bd, n, p0, calls, h_emit, ws, status, saved=saved)
+    hip.gru_chain_bwd(wd, saved, dev(d_emit), n, p0, calls, dgx, dgh, ws, status)
+    torch.cuda.synchronize()
+    assert status.item() == 0
+    xt = torch.tensor(xproj, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w_hh, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b_hh, dtype=torch.float64, requires_grad=True)
+    h = torch.zeros(H, dtype=torch.float64)
+    hs = []
+    for t in range(cols):
+        for i in range(n):
+            hp = wt @ h + bt
+            xr, xz, xn = xt[t * n + i].split(H)
+            hr, hz, hn = hp.split(H)
+            r, z = torch.sigmoid(xr + hr), torch.sigmoid(xz + hz)
+            nn_ = torch.tanh(xn + r * hn)
+            h = (1 - z) * nn_ + z * h
+            hs.append(h)
+    last = torch.stack(hs[-n:])
+    np.testing.assert_allclose(h_emit[0].cpu().numpy(), last.detach().numpy(), rtol=1e-5, atol=2e-6)
+    (last * torch.tensor(d_emit[0], dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(dgx.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=1e-6)       # d/d x-side pre-activations
+    np.testing.assert_allclose(dgh.sum(0).cpu().numpy(), bt.grad.numpy(), rtol=1e-4, atol=1e-5)  # sum over positions = d/d b_hh
+    hprev = torch.zeros(pos, H, device="cuda")
+    hip.chain_hprev(saved, pos, hprev, gru=True)
+    gw = (dgh.double().t() @ hprev.double()).cpu().numpy()
+    np.testing.assert_allclose(gw, wt.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+    m = 37
+    ve, se = rnd(rs, m, 64), rnd(rs, m, 64)
+    S = dev((ve @ se.T).astype(np.float32))
+    loss, dS, rows = torch.zeros(1, device="cuda"), torch.zeros(m, m, device="cuda"), torch.zeros(m, device="cuda")
+    hip.vse_loss(S, 0.2, rows, loss, dS)
+    St = S.cpu().double().requires_grad_(True)
+    margin = (0.2 / m) * (torch.ones(m, m, dtype=torch.float64) - torch.eye(m, dtype=torch.float64))
+    want = (torch.relu(St - torch.diag(St).unsqueeze(1) + margin).sum()
+            + torch.relu(St.t() - torch.diag(St).unsqueeze(1) + margin).sum()) / m
+    want.backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item())
+    np.testing.assert_allclose(dS.cpu().numpy(), St.grad.numpy(), rtol=1e-6, atol=1e-7)

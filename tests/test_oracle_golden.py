@@ -135,6 +135,16 @@ def test_pretraining_steps_match_reference():
         val = orc.adam_update(val, grads, state, lr=1e-3)
     for k, v in val.items():
         check_summary(g, "value_after", k, v, 1e-5, 2e-6)
+    # reward: visual-semantic embedding loss through the batch-1 GRU chain, Adam(1e-4)
+    _, _, rew = params_for(cfg)
+    state = {}
+    for step in range(2):
+        rows = g["reward_rows"][step]
+        loss, grads = orc.reward_vse_step(rew, data["train_features"][rows], data["train_captions"][rows])
+        assert abs(loss - g["reward_losses"][step]) <= 1e-3 * abs(loss), (step, loss)
+        rew = orc.adam_update(rew, grads, state, lr=1e-4)
+    for k, v in rew.items():
+        check_summary(g, "reward_after", k, v, 1e-5, 2e-6)
 
 
 def test_curriculum_skips_short_captions():
