@@ -366,38 +366,53 @@ def train_reward_network(train_data, network_paths, plot_dir, bidirectional, epo
     return reward_network
 
 
-def _load_or_fail(net, path, what):
+def _load_or_train(make, path, what, train):
+    """A pre-trained network from its checkpoint, or - when the file is missing - from its
+    pre-training loop, as trainers.py:345-370 does."""
     try:
+        net = make()
         net.load_state_dict(torch.load(path, map_location=device, weights_only=True), strict=False)
-    except FileNotFoundError as e:
-        raise FileNotFoundError(
-            "%s checkpoint %r not found; the reference would now pre-train it (trainers.py:345-370), "
-            "but the supervised pre-training loops are outside the A2C hot path built here" % (what, path)) from e
-    print(f'[Training] loaded {what}')
-    return net
+        print(f'[Training] loaded {what}')
+        return net
+    except FileNotFoundError:
+        print(f'[Training] {what} not found')
+        return train()
 
 
 def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirectional, epochs, batch_size,
                       retrain_all=False, curriculum=None):
-    """Entry point (trainers.py:312-399): load the three pre-trained networks, freeze the
-    reward network, Adam(lr=1e-4) over value + policy, dispatch to the plain or the
-    curriculum loop, append the network description to the results file."""
-    if retrain_all:
-        raise NotImplementedError("retrain_all runs the supervised pre-training loops "
-                                  "(trainers.py:125-309), which are outside the A2C hot path built here")
+    """Entry point (trainers.py:312-399): the three pre-trained networks are loaded from their
+    checkpoints (or trained by their pre-training loops when a file is missing, or all of them with
+    retrain_all), the reward network is frozen, Adam(lr=1e-4) runs over value + policy, the plain or
+    the curriculum loop is dispatched and the network description is appended to the results file."""
     model_save_path = save_paths["model_path"]
     results_save_path = save_paths["results_path"]
     w2i, emb = train_data["word_to_idx"], train_data["embeddings"]
     fdim = int(np.asarray(train_data["train_features"]).shape[1])
-    reward_network = _load_or_fail(RewardNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional,
-                                                 feature_dim=fdim).to(device),
-                                   network_paths["reward_network"], "reward network")
-    policy_network = _load_or_fail(PolicyNetwork(w2i, input_dim=fdim, pretrained_embeddings=emb,
-                                                 bidirectional=bidirectional).to(device),
-                                   network_paths["policy_network"], "policy network")
-    value_network = _load_or_fail(ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional,
-                                               feature_dim=fdim).to(device),
-                                  network_paths["value_network"], "value network")
+
+    def train_reward():
+        return train_reward_network(train_data, network_paths, plot_dir, bidirectional, batch_size=batch_size)
+
+    def train_policy():
+        return train_policy_network(train_data, network_paths, plot_dir, bidirectional, batch_size=batch_size)
+
+    def train_value():
+        return train_value_network(train_data, network_paths, plot_dir, bidirectional, batch_size=batch_size)
+
+    if retrain_all:
+        print_green('[Training] Training all the networks')
+        reward_network, policy_network, value_network = train_reward(), train_policy(), train_value()
+        print_green('[Training] All networks trained')
+    else:
+        reward_network = _load_or_train(
+            lambda: RewardNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device),
+            network_paths["reward_network"], "reward network", train_reward)
+        policy_network = _load_or_train(
+            lambda: PolicyNetwork(w2i, input_dim=fdim, pretrained_embeddings=emb, bidirectional=bidirectional).to(device),
+            network_paths["policy_network"], "policy network", train_policy)
+        value_network = _load_or_train(
+            lambda: ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device),
+            network_paths["value_network"], "value network", train_value)
     reward_network.requires_grad_(False)
     reward_network.train(False)
     a2c_network = AdvantageActorCriticNetwork(value_network, policy_network).to(device)

@@ -82,12 +82,28 @@ def test_scalar_log_and_missing_library_message(monkeypatch, tmp_path):
         hip.load()
 
 
-def test_train_a2c_network_refuses_what_is_out_of_scope(tmp_path):
+def test_train_a2c_network_falls_back_to_pretraining(tmp_path, monkeypatch):
+    """A missing checkpoint sends train_a2c_network to that network's pre-training loop, and retrain_all
+    to all three, as trainers.py:337-370 does (the loops themselves need the GPU: they are stubbed here)."""
     data = synthetic.make_train_data(4, 30, 5, 512, 0)
     paths = dict(reward_network=str(tmp_path / "r.pt"), policy_network=str(tmp_path / "p.pt"),
                  value_network=str(tmp_path / "v.pt"), a2c_network=str(tmp_path / "a.pt"))
     save = dict(model_path=str(tmp_path / "m.pt"), results_path=str(tmp_path / "res.txt"))
-    with pytest.raises(FileNotFoundError, match="pre-train"):
+    called = []
+
+    class Stop(Exception):
+        pass
+
+    def stub(name):
+        def run(*a, **k):
+            called.append(name)
+            raise Stop(name)
+        return run
+    for name in ("train_reward_network", "train_policy_network", "train_value_network"):
+        monkeypatch.setattr(trainers, name, stub(name))
+    with pytest.raises(Stop):
         trainers.train_a2c_network(data, save, paths, str(tmp_path), False, 1, 4)
-    with pytest.raises(NotImplementedError):
+    assert called == ["train_reward_network"]
+    with pytest.raises(Stop):
         trainers.train_a2c_network(data, save, paths, str(tmp_path), False, 1, 4, retrain_all=True)
+    assert called == ["train_reward_network", "train_reward_network"]
