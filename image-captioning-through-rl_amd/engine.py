@@ -52,6 +52,40 @@ class A2CStepResult:
         return self
 
 
+class _WarmupLadder:
+    """Where one direction (forward / backward chains) starts in the warm-up ladder.  It moves up when a
+    length is rejected, or accepted with less than 3x margin (before it can fail: the parameters drift
+    slowly from minibatch to minibatch); it probes one rung down after eight accepted minibatches whose
+    seam error sat at the rounding floor (less than 6 % of the tolerance), and a probe that does not hold
+    is not repeated for a while (32 minibatches, doubling up to 1024)."""
+
+    def __init__(self):
+        self.first, self.calm, self.cooldown, self.penalty, self.probing = 0, 0, 0, 32, False
+
+    def accepted(self, idx, checks, last):
+        if idx != self.first or not checks:
+            return
+        worst = max(e / t if t > 0 else float("inf") for e, t in checks)
+        self.cooldown = max(0, self.cooldown - 1)
+        if worst > 0.3:
+            self.first, self.calm = min(idx + 1, last), 0
+            if self.probing:
+                self._probe_failed()
+        else:
+            self.probing = False
+            self.calm = self.calm + 1 if worst < 0.06 else 0
+            if self.calm >= 8 and self.cooldown == 0 and self.first > 0:
+                self.first, self.calm, self.probing = self.first - 1, 0, True
+
+    def rejected(self, new_idx):
+        if self.probing:
+            self._probe_failed()
+        self.first, self.calm = new_idx, 0
+
+    def _probe_failed(self):
+        self.probing, self.cooldown, self.penalty = False, self.penalty, min(2 * self.penalty, 1024)
+
+
 class A2CEngine:
     SEAM_TOL_FWD = 1e-5   # max |state_warm - state_true| / max(1, |state_true|) over h and c
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
@@ -72,10 +106,7 @@ class A2CEngine:
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
-        # where each direction starts in the warm-up ladder: a length that failed once, or came close to
-        # failing, is not tried first again (the parameters drift slowly from step to step)
-        self._first_fwd = 0
-        self._first_bwd = 0
+        self._ladder_fwd, self._ladder_bwd = _WarmupLadder(), _WarmupLadder()
         self.last_seam = None
         self._ws = {}
         self._side = None
@@ -359,7 +390,7 @@ class A2CEngine:
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
         last = len(plans) - 1
-        fi, bi = min(self._first_fwd, last), min(self._first_bwd, last)
+        fi, bi = min(self._ladder_fwd.first, last), min(self._ladder_bwd.first, last)
         with_bwd = backward and mode != hip.GREEDY
         redo_forward = True
         while True:
@@ -379,18 +410,17 @@ class A2CEngine:
             ok_f = all(e <= t for e, t in fwd_checks)
             ok_b = all(e <= t for e, t in bwd_checks)
             if ok_f and ok_b:
-                # a length that only just passed is not tried first on the next minibatch
-                if seg_f and fi == self._first_fwd and any(e > 0.3 * t for e, t in fwd_checks):
-                    self._first_fwd = min(fi + 1, last)
-                if seg_b and bi == self._first_bwd and any(e > 0.3 * t for e, t in bwd_checks):
-                    self._first_bwd = min(bi + 1, last)
+                self._ladder_fwd.accepted(fi, fwd_checks, last)
+                self._ladder_bwd.accepted(bi, bwd_checks, last)
                 break
             self.fallbacks += 1
             redo_forward = not ok_f
             if not ok_f:
-                fi = self._first_fwd = self._next_plan(plans, fi, fwd_checks)
+                fi = self._next_plan(plans, fi, fwd_checks)
+                self._ladder_fwd.rejected(fi)
             if not ok_b:
-                bi = self._first_bwd = self._next_plan(plans, bi, bwd_checks)
+                bi = self._next_plan(plans, bi, bwd_checks)
+                self._ladder_bwd.rejected(bi)
         return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                              ws["rewards"].view(s, n).t().contiguous(), ws["scalars"],
                              ws["entropy"] if self.want_entropy else None, ws["status"],
