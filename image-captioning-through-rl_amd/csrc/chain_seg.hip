@@ -143,10 +143,9 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
         const int j = row0 + (item >> 3), u = u0 + 4 * (item & 7);
         it_state[ii] = 0; it_pos[ii] = 0; it_s[ii] = it_t[ii] = it_i[ii] = 0;
         if (item >= 256 || j >= g.K) continue;
-        const int64_t seg_beg = (int64_t)j * g.Ls;
-        const int64_t pos = seg_beg - g.W + m;
+        const int64_t pos = seg_pos(g, j, m - g.W);
         it_pos[ii] = pos;
-        if (pos < 0 || pos >= min(g.total, seg_beg + g.Ls)) { it_state[ii] = 1; continue; }
+        if (pos < 0 || m - g.W >= g.Ls || pos >= g.total) { it_state[ii] = 1; continue; }
         it_state[ii] = 2;
         locate_fast(g, (int)pos, it_s[ii], it_t[ii], it_i[ii]);
         const float* xr = xproj + ((int64_t)it_t[ii] * g.n + it_i[ii]) * (G * H) + u;
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
         const int item = tid + NT * ii;
         const int rr = item >> 3, uq = 4 * (item & 7);
         const int j = row0 + rr, u = u0 + uq;
-        const int64_t seg_beg = (int64_t)j * g.Ls;
+        const int qs = m - g.W;     // step within the segment: negative during the warm-up
         const int64_t pos = it_pos[ii];
         if (it_state[ii] == 1) {
             st4(h_nxt + (int64_t)j * H + u, zero4());
@@ -269,12 +268,12 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
             float4 c;
             LSTM_CELL4(gi, gf, gg, go, pprev[ii], c, h)
             st4(c_nxt + (int64_t)j * H + u, c);
-            if (pos >= seg_beg && saved) {
+            if (qs >= 0 && saved) {
                 float* sp = saved + pos * (6 * H) + u;
                 st4(sp, gi); st4(sp + H, gf); st4(sp + 2 * H, gg); st4(sp + 3 * H, go); st4(sp + 4 * H, c); st4(sp + 5 * H, h);
             }
-            if (pos == seg_beg - 1) st4(seam_a + (int64_t)j * 2 * H + H + u, c);
-            if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
+            if (qs == -1) st4(seam_a + (int64_t)j * 2 * H + H + u, c);
+            if (qs == g.Ls - 1 && j + 1 < g.K) st4(seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
         } else {
             const float4 xr_ = px[ii][0], xz = px[ii][1], xn = px[ii][2];
             const float4 hr_ = add4(sum_partials(pr), ld4(b_hh + u));
@@ -283,10 +282,10 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
             GRU_CELL4(xr_, xz, xn, hr_, hz, hn, pprev[ii], h)
         }
         st4(h_nxt + (int64_t)j * H + u, h);
-        if (pos >= seg_beg && t == g.p0 + s - 1) st4(h_emit + ((int64_t)s * g.n + i) * H + u, h);
+        if (qs >= 0 && t == g.p0 + s - 1) st4(h_emit + ((int64_t)s * g.n + i) * H + u, h);
         constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
-        if (pos == seg_beg - 1) st4(seam_a + (int64_t)j * SW + u, h);
-        if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(seam_b + (int64_t)(j + 1) * SW + u, h);
+        if (qs == -1) st4(seam_a + (int64_t)j * SW + u, h);
+        if (qs == g.Ls - 1 && j + 1 < g.K) st4(seam_b + (int64_t)(j + 1) * SW + u, h);
     }
 }
 
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(256) void seam_check_fwd(const float* __restrict__ 
 
 // ------------------------------------------------------------------ LSTM backward step
 // State entering position p (walking down): dh = W_hh^T dgates(p+1) and dc (carried).
-// Step mp handles pos = seg_beg + Ls + W - 1 - mp.  final = 1: only the product, written
+// Step mp handles step Ls + W - 1 - mp of every segment.  final = 1: only the product, written
 // to dh_out (the state below each segment's first position, for the seam check).
 __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg_prev, const float* __restrict__ w_hh,
                                                     const float* __restrict__ saved, const float* __restrict__ d_emit,
@@ -338,10 +337,10 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     // fetched before the k loop so that their HBM latency hides under it
     const int rr = tid >> 3, uq = 4 * (tid & 7);
     const int j = row0 + rr, u = u0 + uq;
-    const int64_t seg_beg = (int64_t)j * g.Ls;
-    const int64_t pos = seg_beg + g.Ls + g.W - 1 - mp;
+    const int qs = g.Ls + g.W - 1 - mp;   // step within the segment: >= Ls during the warm-up
+    const int64_t pos = seg_pos(g, j, qs);
     const bool have_row = j < g.K;
-    const bool live = have_row && !final && pos < g.total && seg_beg < g.total;
+    const bool live = have_row && !final && pos < g.total && seg_pos(g, j, 0) < g.total;
     float4 gi = zero4(), gf = zero4(), gg = zero4(), go = zero4(), cc = zero4(), cp = zero4(), de = zero4();
     float4 dcv = zero4();
     if (have_row && !final) dcv = ld4(dc + (int64_t)j * H + u);
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
         locate_fast(g, (int)pos, s, t, i);
         const float* sp = saved + pos * (6 * H) + u;
         gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H); cc = ld4(sp + 4 * H);
-        if (pos > 0) cp = ld4(saved + (pos - 1) * (6 * H) + 4 * H + u);
+        if (pos >= g.stride) cp = ld4(saved + (pos - g.stride) * (6 * H) + 4 * H + u);
         if (t == g.p0 + s - 1) de = ld4(d_emit + ((int64_t)s * g.n + i) * H + u);
     }
 
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
         st4(dh_out + (int64_t)j * H + u, dh);
         return;
     }
-    if (pos == seg_beg + g.Ls - 1) {  // state entering the segment's last own position
+    if (qs == g.Ls - 1) {  // state entering the segment's last own position
         st4(seam_a + (int64_t)j * 2 * H + u, dh);
         st4(seam_a + (int64_t)j * 2 * H + H + u, dcv);
     }
@@ -440,7 +439,7 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     LSTM_BWD4(dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
     st4(dgo, d_i); st4(dgo + H, d_f); st4(dgo + 2 * H, d_g); st4(dgo + 3 * H, d_o);
     st4(dc + (int64_t)j * H + u, dcn);
-    if (pos < seg_beg + g.Ls) {
+    if (qs < g.Ls) {
         float* dp = dgv + pos * (4 * H) + u;
         st4(dp, d_i); st4(dp + H, d_f); st4(dp + 2 * H, d_g); st4(dp + 3 * H, d_o);
     }
@@ -572,8 +571,6 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
     // this thread's epilogue item: segment row j, units u..u+3; its cell state lives in registers
     const int rr = tid >> 3, uq = 4 * (tid & 7);
     const int j = row0 + rr, u = u0 + uq;
-    const int64_t seg_beg = (int64_t)j * g.Ls;
-    const int64_t seg_end = min(g.total, seg_beg + g.Ls);
     float4 state = zero4();            // LSTM: c, GRU: h
     int ps = 0, pt = 0, pi = 0;        // (call, column, row) of the current position
     float4 bias[G == 3 ? 3 : 1];
@@ -585,11 +582,12 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
     const int steps = g.W + g.Ls;
     for (int m = 0; m < steps; ++m) {
         const int cur = m & 1, nxt = cur ^ 1;
-        const int64_t pos = seg_beg - g.W + m;
+        const int qs = m - g.W;     // step within the segment: negative during the warm-up
+        const int64_t pos = seg_pos(g, j, qs);
         int st = 0;   // 0 = no row, 1 = outside the segment's range (zero state), 2 = live
         float4 px[G];
         if (j < g.K) {
-            st = (pos < 0 || pos >= seg_end) ? 1 : 2;
+            st = (pos < 0 || qs >= g.Ls || pos >= g.total) ? 1 : 2;
             if (st == 2) {
                 locate_fast(g, (int)pos, ps, pt, pi);
                 // input projection row: does not depend on the product, its latency hides under the k loop
@@ -710,22 +708,22 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                     float4 c;
                     LSTM_CELL4(gi, gf, gg, go, state, c, h)
                     state = c;
-                    if (pos >= seg_beg && a.saved) {
+                    if (qs >= 0 && a.saved) {
                         float* sp = a.saved + pos * (6 * H) + u;
                         st4(sp, gi); st4(sp + H, gf); st4(sp + 2 * H, gg); st4(sp + 3 * H, go); st4(sp + 4 * H, c); st4(sp + 5 * H, h);
                     }
-                    if (pos == seg_beg - 1) st4(a.seam_a + (int64_t)j * 2 * H + H + u, c);
-                    if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
+                    if (qs == -1) st4(a.seam_a + (int64_t)j * 2 * H + H + u, c);
+                    if (qs == g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
                 } else {
                     const float4 hr_ = add4(sum_partials(pr), bias[0]), hz = add4(sum_partials(pr + 32 * PLD), bias[1]);
                     const float4 hn = add4(sum_partials(pr + 64 * PLD), bias[G == 3 ? 2 : 0]);
                     GRU_CELL4(px[0], px[1], px[2], hr_, hz, hn, state, h)
                     state = h;
                 }
-                if (pos >= seg_beg && pt == g.p0 + ps - 1) st4(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
+                if (qs >= 0 && pt == g.p0 + ps - 1) st4(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
                 constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
-                if (pos == seg_beg - 1) st4(a.seam_a + (int64_t)j * SW + u, h);
-                if (pos == seg_beg + g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * SW + u, h);
+                if (qs == -1) st4(a.seam_a + (int64_t)j * SW + u, h);
+                if (qs == g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * SW + u, h);
             }
             // the exchanged copy of h: write-through, 16 bytes per lane
             __builtin_amdgcn_raw_buffer_store_b128(as_u4(h), rs, (j * H + u) * 4, nxt * g.K * H * 4, SC1);
@@ -816,7 +814,6 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     // this thread's epilogue item and its carried dc
     const int rr = tid >> 3, uq = 4 * (tid & 7);
     const int j = row0 + rr, u = u0 + uq;
-    const int64_t seg_beg = (int64_t)j * g.Ls;
     const bool have_row = j < g.K;
     float4 dcv = zero4();
     int ps = 0, pt = 0, pi = 0;
@@ -826,14 +823,15 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     for (int mp = 0; mp <= steps; ++mp) {
         const bool final = mp == steps;
         const int cur = mp & 1;   // this step writes dgx[cur]; it reads dgx[cur ^ 1]
-        const int64_t pos = seg_beg + g.Ls + g.W - 1 - mp;
-        const bool live = have_row && !final && pos < g.total && seg_beg < g.total;
+        const int qs = g.Ls + g.W - 1 - mp;   // step within the segment: >= Ls during the warm-up
+        const int64_t pos = seg_pos(g, j, qs);
+        const bool live = have_row && !final && pos < g.total && seg_pos(g, j, 0) < g.total;
         float4 gi = zero4(), gf = zero4(), gg = zero4(), go = zero4(), cc = zero4(), cp = zero4(), de = zero4();
         if (live) {
             locate_fast(g, (int)pos, ps, pt, pi);
             const float* sp = a.saved + pos * (6 * H) + u;
             gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H); cc = ld4(sp + 4 * H);
-            if (pos > 0) cp = ld4(a.saved + (pos - 1) * (6 * H) + 4 * H + u);
+            if (pos >= g.stride) cp = ld4(a.saved + (pos - g.stride) * (6 * H) + 4 * H + u);
             if (pt == g.p0 + ps - 1) de = ld4(a.d_emit + ((int64_t)ps * g.n + pi) * H + u);
         }
 
@@ -902,7 +900,7 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
                 st4(a.dh_fin + (int64_t)j * H + u, dh);
                 st4(a.dc + (int64_t)j * H + u, dcv);
             } else {
-                if (pos == seg_beg + g.Ls - 1) {  // state entering the segment's last own position
+                if (qs == g.Ls - 1) {  // state entering the segment's last own position
                     st4(a.seam_a + (int64_t)j * 2 * H + u, dh);
                     st4(a.seam_a + (int64_t)j * 2 * H + H + u, dcv);
                 }
@@ -910,7 +908,7 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
                 if (live) {
                     dh = add4(dh, de);
                     LSTM_BWD4(dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
-                    if (pos < seg_beg + g.Ls) {
+                    if (qs < g.Ls) {
                         float* dp = a.dgv + pos * (4 * H) + u;
                         st4(dp, d_i); st4(dp + H, d_f); st4(dp + 2 * H, d_g); st4(dp + 3 * H, d_o);
                     }
@@ -944,6 +942,97 @@ __global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* s
 }
 int seam_blocks(int64_t elems) { return (int)std::min<int64_t>(128, (elems + 255) / 256); }
 
+// a launch that gave up waiting, reported through a status word (the per-row chains have no seam error)
+__global__ void flag_on_abort(const unsigned* abort_w, int* status) {
+    if (*abort_w != 0) *status = 1;
+}
+
+// Workspace layouts (floats, kh = K * 512), K segments:
+//   forward LSTM : h[2][kh], c[2][kh], seam_a[2 kh], seam_b[2 kh]
+//   forward GRU  : h[2][kh], seam_a[kh], seam_b[kh]
+//   backward     : dgates[2][4 kh], dc[kh], seam_a[2 kh], dh_fin[kh]
+//   all          : polled words of the persistent launches from 12 kh
+int fwd_steps_lstm(const Geom& g, const float* xproj, const float* w_hh, float* h_emit, float* saved, float* work,
+                    hipStream_t st) {
+    const int64_t kh = (int64_t)g.K * H;
+    float* hb[2] = {work, work + kh};
+    float* cb[2] = {work + 2 * kh, work + 3 * kh};
+    ICRL_HIP(hipMemsetAsync(work, 0, sizeof(float) * 4 * kh, st));
+    const dim3 grid(H / 32, (g.K + 31) / 32);
+    for (int m = 0; m < g.W + g.Ls; ++m) {
+        const int cur = m & 1;
+        hipLaunchKernelGGL(seg_fwd_step<4>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, (const float*)nullptr,
+                           cb[cur], cb[cur ^ 1], hb[cur ^ 1], saved, h_emit, work + 4 * kh, work + 6 * kh, g, m);
+    }
+    return ICRL_OK;
+}
+
+int fwd_steps_gru(const Geom& g, const float* xproj, const float* w_hh, const float* b_hh, float* h_emit,
+                   float* work, hipStream_t st) {
+    const int64_t kh = (int64_t)g.K * H;
+    float* hb[2] = {work, work + kh};
+    ICRL_HIP(hipMemsetAsync(work, 0, sizeof(float) * 2 * kh, st));
+    const dim3 grid(H / 32, (g.K + 31) / 32);
+    for (int m = 0; m < g.W + g.Ls; ++m) {
+        const int cur = m & 1;
+        hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
+                           (float*)nullptr, hb[cur ^ 1], (float*)nullptr, h_emit, work + 2 * kh, work + 3 * kh, g, m);
+    }
+    return ICRL_OK;
+}
+
+int bwd_steps(const Geom& g, const float* w_hh, const float* saved, const float* d_emit, float* dgates, float* work,
+               hipStream_t st) {
+    const int64_t kh = (int64_t)g.K * H;
+    float* dg[2] = {work, work + 4 * kh};
+    float* dc = work + 8 * kh;
+    float* seam_a = work + 9 * kh;
+    float* dh_fin = work + 11 * kh;
+    ICRL_HIP(hipMemsetAsync(dc, 0, sizeof(float) * 3 * kh, st));
+    const dim3 grid(H / 32, (g.K + 31) / 32);
+    const int steps = g.W + g.Ls;
+    for (int mp = 0; mp < steps; ++mp)
+        hipLaunchKernelGGL(seg_bwd_step, grid, dim3(256), 0, st, dg[(mp & 1) ^ 1], w_hh, saved, d_emit, dc, dg[mp & 1],
+                           dgates, seam_a, dh_fin, g, mp, 0);
+    hipLaunchKernelGGL(seg_bwd_step, grid, dim3(256), 0, st, dg[(steps & 1) ^ 1], w_hh, saved, d_emit, dc,
+                       dg[steps & 1], dgates, seam_a, dh_fin, g, steps, 1);
+    return ICRL_OK;
+}
+
+// both forward chains in one persistent launch; returns the abort word through *abort_out
+int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipStream_t st, unsigned** abort_out) {
+    const int K = v.g.K;
+    const int64_t kh = (int64_t)K * H;
+    const int ny = (K + 31) / 32;
+    // polled words (flags of both chains, abort word): a block of their own, zeroed on every call
+    unsigned* words = reinterpret_cast<unsigned*>(work_v + 12 * kh);
+    const size_t word_bytes = ((size_t)(2 * ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
+    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+    ICRL_HIP(hipMemsetAsync(work_v, 0, sizeof(float) * 2 * kh, st));
+    ICRL_HIP(hipMemsetAsync(work_r, 0, sizeof(float) * 2 * kh, st));
+    v.hb = work_v; v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
+    r.hb = work_r; r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 16;
+    *abort_out = words + 2 * ny * 16;
+    const int per_chain = (H / 32) * ny;
+    hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, *abort_out, per_chain);
+    return ICRL_OK;
+}
+
+int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out) {
+    const int K = a.g.K;
+    const int64_t kh = (int64_t)K * H;
+    const int ny = (K + 31) / 32;
+    unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
+    const size_t word_bytes = ((size_t)(ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
+    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+    a.dgx = work; a.dc = work + 8 * kh; a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
+    *abort_out = words + ny * 16;
+    hipLaunchKernelGGL(seg_bwd_persist, dim3(16 * ny), dim3(256), 0, st, a, *abort_out);
+    return ICRL_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64_t)segments * 16 * H; }
@@ -958,21 +1047,10 @@ extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, in
                  "icrl_lstm_chain_fwd_seg: buffers must be 16-byte aligned");
     hipStream_t st = icrl::as_stream(stream);
     const int64_t kh = (int64_t)g.K * H;
-    float* hb[2] = {work, work + kh};
-    float* cb[2] = {work + 2 * kh, work + 3 * kh};
-    float* seam_a = work + 4 * kh;        // [K, 2H]
-    float* seam_b = work + 6 * kh;        // [K, 2H]
-    ICRL_HIP(hipMemsetAsync(work, 0, sizeof(float) * 4 * kh, st));
     ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
-    const dim3 grid(H / 32, (g.K + 31) / 32);
-    const int steps = g.W + g.Ls;
-    for (int m = 0; m < steps; ++m) {
-        const int cur = m & 1;
-        hipLaunchKernelGGL(seg_fwd_step<4>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, (const float*)nullptr,
-                           cb[cur], cb[cur ^ 1], hb[cur ^ 1], saved, h_emit, seam_a, seam_b, g, m);
-    }
-    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, seam_a, seam_b, g, 2 * H,
-                       seam_err);
+    if (int rc = fwd_steps_lstm(g, xproj, w_hh, h_emit, saved, work, st)) return rc;
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, work + 4 * kh, work + 6 * kh,
+                       g, 2 * H, seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -987,19 +1065,10 @@ extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, con
                  "icrl_gru_chain_fwd_seg: buffers must be 16-byte aligned");
     hipStream_t st = icrl::as_stream(stream);
     const int64_t kh = (int64_t)g.K * H;
-    float* hb[2] = {work, work + kh};
-    float* seam_a = work + 2 * kh;        // [K, H]
-    float* seam_b = work + 3 * kh;        // [K, H]
-    ICRL_HIP(hipMemsetAsync(work, 0, sizeof(float) * 2 * kh, st));
     ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
-    const dim3 grid(H / 32, (g.K + 31) / 32);
-    const int steps = g.W + g.Ls;
-    for (int m = 0; m < steps; ++m) {
-        const int cur = m & 1;
-        hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
-                           (float*)nullptr, hb[cur ^ 1], (float*)nullptr, h_emit, seam_a, seam_b, g, m);
-    }
-    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * H)), dim3(256), 0, st, seam_a, seam_b, g, H, seam_err);
+    if (int rc = fwd_steps_gru(g, xproj, w_hh, b_hh, h_emit, work, st)) return rc;
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * H)), dim3(256), 0, st, work + 2 * kh, work + 3 * kh, g, H,
+                       seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -1014,21 +1083,10 @@ extern "C" int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, co
                  "icrl_lstm_chain_bwd_seg: buffers must be 16-byte aligned");
     hipStream_t st = icrl::as_stream(stream);
     const int64_t kh = (int64_t)g.K * H;
-    float* dg[2] = {work, work + 4 * kh}; // [K, 4H] each
-    float* dc = work + 8 * kh;            // [K, H]
-    float* seam_a = work + 9 * kh;        // [K, 2H]
-    float* dh_fin = work + 11 * kh;       // [K, H]
-    ICRL_HIP(hipMemsetAsync(dc, 0, sizeof(float) * 3 * kh, st));
     ICRL_HIP(hipMemsetAsync(seam_err, 0, 2 * sizeof(float), st));
-    const dim3 grid(H / 32, (g.K + 31) / 32);
-    const int steps = g.W + g.Ls;
-    for (int mp = 0; mp < steps; ++mp)
-        hipLaunchKernelGGL(seg_bwd_step, grid, dim3(256), 0, st, dg[(mp & 1) ^ 1], w_hh, saved, d_emit, dc, dg[mp & 1],
-                           dgates, seam_a, dh_fin, g, mp, 0);
-    hipLaunchKernelGGL(seg_bwd_step, grid, dim3(256), 0, st, dg[(steps & 1) ^ 1], w_hh, saved, d_emit, dc,
-                       dg[steps & 1], dgates, seam_a, dh_fin, g, steps, 1);
-    hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, seam_a, dh_fin, dc, g,
-                       seam_err, seam_err + 1);
+    if (int rc = bwd_steps(g, w_hh, saved, d_emit, dgates, work, st)) return rc;
+    hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, work + 9 * kh, work + 11 * kh,
+                       work + 8 * kh, g, seam_err, seam_err + 1);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -1037,7 +1095,7 @@ extern "C" int icrl_chain_pair_supported(int segments) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return segments >= 2 && (H / 32) * ((segments + 31) / 32) <= cus ? 1 : 0;   // two workgroups (80 KB of LDS each) per CU
+    return segments >= 1 && (H / 32) * ((segments + 31) / 32) <= cus ? 1 : 0;   // two workgroups (80 KB of LDS each) per CU
 }
 
 extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
@@ -1057,24 +1115,12 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
                  "icrl_chain_pair_fwd_seg: %d segments need more workgroups than the device has CUs; its workgroups "
                  "wait for each other and must all be resident", segments);
     hipStream_t st = icrl::as_stream(stream);
-    const int64_t kh = (int64_t)segments * H;
-    const int ny = (segments + 31) / 32;
-    // polled words (flags of both chains, abort word): a block of their own, zeroed on every call
-    unsigned* words = reinterpret_cast<unsigned*>(work_v + 12 * kh);
-    const size_t word_bytes = ((size_t)(2 * ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
-    ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "icrl_chain_pair_fwd_seg: workspace too small");
-    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
-    ICRL_HIP(hipMemsetAsync(work_v, 0, sizeof(float) * 2 * kh, st));
-    ICRL_HIP(hipMemsetAsync(work_r, 0, sizeof(float) * 2 * kh, st));
     ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
     ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
-    v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.hb = work_v; v.saved = saved_v; v.h_emit = h_emit_v;
-    v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
-    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.hb = work_r; r.saved = nullptr; r.h_emit = h_emit_r;
-    r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 16;
-    unsigned* abort_w = words + 2 * ny * 16;
-    const int per_chain = (H / 32) * ny;
-    hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, abort_w, per_chain);
+    v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v;
+    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = nullptr; r.h_emit = h_emit_r;
+    unsigned* abort_w = nullptr;
+    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(v.g.K * 2 * H)), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
                        2 * H, seam_err_v);
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(r.g.K * H)), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
@@ -1096,19 +1142,75 @@ extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* s
                  "icrl_lstm_chain_bwd_seg_persist: %d segments need more workgroups than the device has CUs; its "
                  "workgroups wait for each other and must all be resident", segments);
     hipStream_t st = icrl::as_stream(stream);
-    const int64_t kh = (int64_t)segments * H;
-    const int ny = (segments + 31) / 32;
-    unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
-    const size_t word_bytes = ((size_t)(ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
-    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
     ICRL_HIP(hipMemsetAsync(seam_err, 0, 2 * sizeof(float), st));
-    a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgx = work; a.dc = work + 8 * kh; a.dgv = dgates;
-    a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
-    unsigned* abort_w = words + ny * 16;
-    hipLaunchKernelGGL(seg_bwd_persist, dim3(16 * ny), dim3(256), 0, st, a, abort_w);
+    a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgv = dgates;
+    unsigned* abort_w = nullptr;
+    if (int rc = bwd_persist(a, work, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
                        a.g, seam_err, seam_err + 1);
     hipLaunchKernelGGL(poison_on_abort1, dim3(1), dim3(1), 0, st, abort_w, seam_err);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+// ------------------------------------------------------------------ every row its own chain
+// The recurrences as a per-image model would run them (the reference's own classes at batch size 1): row i
+// walks its own columns, call after call, from a zero state, independently of the other rows.  The N
+// chains advance together through the same kernels as the segments above (a "segment" is a row, no
+// warm-up, no seams), with the same per-position layouts, so everything downstream is shared.
+extern "C" int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                        const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                                        int n_calls, int persistent, float* h_emit_v, float* saved_v,
+                                        float* h_emit_r, float* work_v, float* work_r, int* status,
+                                        icrl_stream_t stream) {
+    ChainArgs v, r;
+    if (int rc = make_geom_rows("icrl_chain_pair_fwd_rows", N, p0_v, n_calls, v.g)) return rc;
+    if (int rc = make_geom_rows("icrl_chain_pair_fwd_rows", N, p0_r, n_calls, r.g)) return rc;
+    ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r && status,
+                 "icrl_chain_pair_fwd_rows: null pointer");
+    ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(xproj_r) && aligned16(w_hh_r) &&
+                 aligned16(b_hh_r) && aligned16(h_emit_v) && aligned16(saved_v) && aligned16(h_emit_r) &&
+                 aligned16(work_v) && aligned16(work_r), "icrl_chain_pair_fwd_rows: buffers must be 16-byte aligned");
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    if (persistent) {
+        ICRL_REQUIRE(icrl_chain_pair_supported(N),
+                     "icrl_chain_pair_fwd_rows: %d rows need more workgroups than the device has CUs for a persistent "
+                     "launch; pass persistent = 0", N);
+        v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v;
+        r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = nullptr; r.h_emit = h_emit_r;
+        unsigned* abort_w = nullptr;
+        if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
+        hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+    } else {
+        if (int rc = fwd_steps_lstm(v.g, xproj_v, w_hh_v, h_emit_v, saved_v, work_v, st)) return rc;
+        if (int rc = fwd_steps_gru(r.g, xproj_r, w_hh_r, b_hh_r, h_emit_r, work_r, st)) return rc;
+    }
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_lstm_chain_bwd_rows(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                                        int n_calls, int persistent, float* dgates, float* work, int* status,
+                                        icrl_stream_t stream) {
+    BwdArgs a;
+    if (int rc = make_geom_rows("icrl_lstm_chain_bwd_rows", N, p0, n_calls, a.g)) return rc;
+    ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && status, "icrl_lstm_chain_bwd_rows: null pointer");
+    ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),
+                 "icrl_lstm_chain_bwd_rows: buffers must be 16-byte aligned");
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    if (persistent) {
+        ICRL_REQUIRE(icrl_chain_pair_supported(N),
+                     "icrl_lstm_chain_bwd_rows: %d rows need more workgroups than the device has CUs for a persistent "
+                     "launch; pass persistent = 0", N);
+        a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgv = dgates;
+        unsigned* abort_w = nullptr;
+        if (int rc = bwd_persist(a, work, st, &abort_w)) return rc;
+        hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+    } else {
+        if (int rc = bwd_steps(a.g, w_hh, saved, d_emit, dgates, work, st)) return rc;
+    }
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

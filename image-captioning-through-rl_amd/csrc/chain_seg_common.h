@@ -21,7 +21,15 @@ struct Geom {
     int n, p0, n_calls;   // rows per column, columns in the first call, calls
     int64_t total;        // positions in the chain
     int K, Ls, W;         // segments, positions per segment, warm-up steps
+    int stride;           // positions between consecutive steps of a segment: 1, or n when every row is its own chain
 };
+
+// Position of step q of segment j (0 <= q < Ls: its own positions, q < 0: warm-up before them, q >= Ls:
+// warm-up after them).  stride 1: the batch-1 chain cut into K runs of Ls consecutive positions.
+// stride n: K = n independent chains, one per row, each walking its row's positions column by column.
+__device__ __forceinline__ int64_t seg_pos(const Geom& g, int j, int q) {
+    return g.stride == 1 ? (int64_t)j * g.Ls + q : (int64_t)q * g.n + j;
+}
 
 // position -> (call s, column t, row i)
 __device__ __forceinline__ void locate(const Geom& g, int64_t pos, int& s, int& t, int& i) {
@@ -112,6 +120,20 @@ inline int make_geom(const char* who, int N, int p0, int n_calls, int segments, 
     g.K = segments;
     g.Ls = (int)((g.total + segments - 1) / segments);
     g.W = warmup;
+    g.stride = 1;
+    return ICRL_OK;
+}
+
+// every row its own chain over its columns (call after call), from a zero state: N "segments" of
+// cols positions each, no warm-up, no seams
+inline int make_geom_rows(const char* who, int N, int p0, int n_calls, Geom& g) {
+    ICRL_REQUIRE(N > 0 && N <= 4096 && p0 > 0 && n_calls > 0, "%s: need 0 < N <= 4096, p0 > 0, n_calls > 0", who);
+    g.n = N; g.p0 = p0; g.n_calls = n_calls;
+    int64_t cols = 0;
+    for (int s = 0; s < n_calls; ++s) cols += p0 + s;
+    g.total = cols * N;
+    ICRL_REQUIRE(g.total < (int64_t)1 << 30, "%s: chains of 2^30 or more positions are not supported", who);
+    g.K = N; g.Ls = (int)cols; g.W = 0; g.stride = N;
     return ICRL_OK;
 }
 

@@ -366,15 +366,16 @@ __global__ __launch_bounds__(256) void chain_fold_kernel(const float* __restrict
     }
 }
 
-// h_prev[pos,:] = saved[pos-1, h_slot] (zeros at pos 0); `slots` x 512 floats per position
+// h_prev[pos,:] = saved[pos-stride, h_slot] (zeros for pos < stride); `slots` x 512 floats per position
 __global__ __launch_bounds__(256) void chain_hprev_kernel(const float* __restrict__ saved, int64_t positions,
-                                                          int slots, int h_slot, float4* __restrict__ h_prev) {
+                                                          int slots, int h_slot, int64_t stride,
+                                                          float4* __restrict__ h_prev) {
     const int64_t total = positions * (H / 4);
     for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t pos = e / (H / 4);
         const int c = (int)(e % (H / 4));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pos > 0) v = reinterpret_cast<const float4*>(saved + ((pos - 1) * slots + h_slot) * H)[c];
+        if (pos >= stride) v = reinterpret_cast<const float4*>(saved + ((pos - stride) * slots + h_slot) * H)[c];
         h_prev[e] = v;
     }
 }
@@ -540,11 +541,11 @@ extern "C" int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_c
     return ICRL_OK;
 }
 
-extern "C" int icrl_chain_hprev(const float* saved, int64_t positions, int gru, float* h_prev,
+extern "C" int icrl_chain_hprev(const float* saved, int64_t positions, int gru, int64_t stride, float* h_prev,
                                 icrl_stream_t stream) {
-    ICRL_REQUIRE(saved && h_prev && positions > 0, "icrl_chain_hprev: bad argument");
+    ICRL_REQUIRE(saved && h_prev && positions > 0 && stride >= 1, "icrl_chain_hprev: bad argument");
     hipLaunchKernelGGL(chain_hprev_kernel, dim3(grid_for(positions * (H / 4), 256)), dim3(256), 0,
-                       as_stream(stream), saved, positions, gru ? 5 : 6, gru ? 4 : 5,
+                       as_stream(stream), saved, positions, gru ? 5 : 6, gru ? 4 : 5, stride,
                        reinterpret_cast<float4*>(h_prev));
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;

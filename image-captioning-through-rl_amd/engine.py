@@ -25,6 +25,12 @@ The two recurrences can be evaluated in two ways (``chain_mode``):
     run in one launch, and all steps of the backward chain in another;
   * "auto" (default): segmented for chains of at least 8192 positions, else exact.
 
+``chain_semantics="per_sample"`` is an explicit change of what is computed, never a default: every
+image owns its recurrent state (the reference's own classes called with one image at a time,
+state kept across the calls of a minibatch), so row i's values and rewards no longer depend on the
+rows before it.  The N chains then advance together, one [N,512] x W_hh product per step, through
+the same kernels (a "segment" is a row: no warm-up, no seams, nothing approximate).
+
 All device memory is PyTorch-owned and cached per problem shape; nothing here touches
 the CPU oracle, and every kernel call raises if libicrl_a2c.so is missing.
 """
@@ -93,6 +99,7 @@ class A2CEngine:
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
+                 chain_semantics="batch",
                  warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
@@ -103,6 +110,8 @@ class A2CEngine:
         self.want_entropy = entropy  # per-(step,row) policy entropy: a diagnostic, not part of the loss
         self.persistent = persistent  # persistent chain kernels (one launch for all steps) when the device can hold them
         assert chain_mode in ("auto", "exact", "segmented")
+        assert chain_semantics in ("batch", "per_sample")
+        self.per_sample = chain_semantics == "per_sample"
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
@@ -178,7 +187,7 @@ class A2CEngine:
         # 5 of an activation gradient
         scratch = max(16 * 4 * H * H, 8 * (self.vocab or 0) * H, 5 * l_cols * n * max(widths))
         ws["scratch_main"], ws["scratch_side"] = f32(scratch), f32(scratch)
-        k = self._segments_for(tv)
+        k = n if self.per_sample else self._segments_for(tv)
         if k:
             ws["work_v"] = f32(hip.chain_seg_workspace_floats(k))
             ws["work_r"] = f32(hip.chain_seg_workspace_floats(k))
@@ -197,6 +206,8 @@ class A2CEngine:
         return max(32, min(512, positions // 16 // 32 * 32))
 
     def _plans(self, ws):
+        if self.per_sample:
+            return [("rows",)]
         k = ws["segments"]
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
@@ -430,11 +441,12 @@ class A2CEngine:
         P, V, R = self.P, self.V, self.R
         t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
         tok_flat = ws["tokT"].view(-1)
-        seg = plan[0] == "segmented"
+        seg, rows = plan[0] == "segmented", plan[0] == "rows"
 
         # ---- 2. the two forward chains: one persistent launch for both when the device can hold it,
         # else the reward GRU chain on the side stream beside the value LSTM chain on the main stream
-        pair = seg and self.persistent and hip.chain_pair_supported(plan[1])
+        # (per-row chains: always one call for both, persistent or a launch per step)
+        pair = rows or (seg and self.persistent and hip.chain_pair_supported(plan[1]))
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
@@ -460,10 +472,17 @@ class A2CEngine:
                  bias2=V["valrnn.lstm.bias_hh_l0"])
         if pair:
             main.wait_event(ev_xpr)
+        if rows:
+            hip.chain_pair_fwd_rows(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
+                                    R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, ws["hv"],
+                                    ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
+                                    ws["status"][0:1], persistent=self.persistent and hip.chain_pair_supported(n))
+        elif pair:
             hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
                                    R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
                                    ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
                                    ws["seam"][0:2], ws["seam"][2:4])
+        if pair:
             ev_pair = torch.cuda.Event()
             ev_pair.record(main)
             with torch.cuda.stream(side):
@@ -539,7 +558,12 @@ class A2CEngine:
         V, gV = self.V, self.gV
         lv, tv = p0 + s - 1, ws["tv"]
         tok_flat = ws["tokT"].view(-1)
-        if plan[0] == "segmented":
+        hprev_stride = n if plan[0] == "rows" else 1
+        if plan[0] == "rows":
+            hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
+                                    ws["work_v"], ws["status"][2:3],
+                                    persistent=self.persistent and hip.chain_pair_supported(n))
+        elif plan[0] == "segmented":
             hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, plan[1], plan[2],
                                    ws["dgv"], ws["work_v"], ws["seam"][4:6],
                                    persistent=self.persistent and hip.chain_pair_supported(plan[1]))
@@ -555,7 +579,7 @@ class A2CEngine:
         with torch.cuda.stream(side):
             if ev_loss is not None:
                 side.wait_event(ev_loss)
-                hip.chain_hprev(ws["saved"], tv, ws["hprev"])
+                hip.chain_hprev(ws["saved"], tv, ws["hprev"], stride=hprev_stride)
                 ev_hprev = torch.cuda.Event()
                 ev_hprev.record(side)
                 self._mark("side:policy_bwd_start")

@@ -32,6 +32,8 @@ SIGNATURES = {
     "icrl_chain_pair_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp] * 8),
+    "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
+    "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
@@ -51,7 +53,7 @@ SIGNATURES = {
     "icrl_vse_loss": (c_int, [c_vp, c_int, ctypes.c_float, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_fold_calls": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
-    "icrl_chain_hprev": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    "icrl_chain_hprev": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
     "icrl_value_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_cosine_reward": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_a2c_loss": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -287,9 +289,9 @@ def chain_fold_calls(dgates, n, p0, n_calls, width, out):
            "icrl_chain_fold_calls")
 
 
-def chain_hprev(saved, positions, h_prev, gru=False):
-    _check(load().icrl_chain_hprev(_ptr(_f32c(saved)), positions, int(gru), _ptr(_f32c(h_prev)), _stream()),
-           "icrl_chain_hprev")
+def chain_hprev(saved, positions, h_prev, gru=False, stride=1):
+    _check(load().icrl_chain_hprev(_ptr(_f32c(saved)), positions, int(gru), int(stride), _ptr(_f32c(h_prev)),
+                                   _stream()), "icrl_chain_hprev")
 
 
 def value_head_fwd(yh_inout, u, w2, b2, rows, n, values):
@@ -422,6 +424,28 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
                                             _ptr(_f32c(h_emit_r)), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
                                             _ptr(seam_err_v), _ptr(seam_err_r), _stream())
     _check(rc, "icrl_chain_pair_fwd_seg")
+
+
+def chain_pair_fwd_rows(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, h_emit_v, saved_v, h_emit_r,
+                        work_v, work_r, status, persistent=True):
+    """Value LSTM and reward GRU with every row its own chain (the reference's classes at batch size 1)."""
+    assert status.dtype == torch.int32
+    with _Timed("chain_pair_fwd", chain_positions(1, p0_v, n_calls) + chain_positions(1, p0_r, n_calls)):
+        rc = load().icrl_chain_pair_fwd_rows(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
+                                             _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls,
+                                             int(persistent), _ptr(_f32c(h_emit_v)), _ptr(saved_v),
+                                             _ptr(_f32c(h_emit_r)), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
+                                             _ptr(status), _stream())
+    _check(rc, "icrl_chain_pair_fwd_rows")
+
+
+def lstm_chain_bwd_rows(w_hh, saved, d_emit, n, p0, n_calls, dgates, work, status, persistent=True):
+    assert status.dtype == torch.int32
+    with _Timed("lstm_chain_bwd", chain_positions(1, p0, n_calls)):
+        rc = load().icrl_lstm_chain_bwd_rows(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
+                                             int(persistent), _ptr(_f32c(dgates)), _ptr(_f32c(work)), _ptr(status),
+                                             _stream())
+    _check(rc, "icrl_lstm_chain_bwd_rows")
 
 
 def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False):

@@ -196,11 +196,14 @@ def _a2c_minibatch(engine, optimizer, captions, features, p0, n_steps):
     return res
 
 
-def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size, epochs):
-    """Advantage-weighted policy-gradient training (trainers.py:402-500)."""
+def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size, epochs,
+                 chain_semantics="batch"):
+    """Advantage-weighted policy-gradient training (trainers.py:402-500).  chain_semantics="per_sample"
+    gives every image its own recurrent state in the value / reward networks (what the reference
+    computes at batch_size 1) instead of one recurrence through all rows of the minibatch."""
     writer = make_writer(plot_dir)
     print_green('[Training] Training Advantage Actor-Critic Network')
-    engine = build_engine(a2c_network, reward_network)
+    engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics)
     best_loss = float('inf')
     for epoch in range(epochs):
         for minibatch_id, (captions, features, _) in enumerate(
@@ -220,14 +223,14 @@ def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, s
 
 
 def a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size,
-                            epochs, curriculum):
+                            epochs, curriculum, chain_semantics="batch"):
     """Curriculum variant (trainers.py:503-616): for each level, start from the
     ground-truth prefix captions[:, :caplen-level] and roll out `level` steps; minibatches
     whose captions are too short for the level are skipped."""
     writer = make_writer(plot_dir)
     print_green('[Training] Training Advantage Actor-Critic Network')
     print_green(f'[Training] mode set to curriculum training using levels: {curriculum}')
-    engine = build_engine(a2c_network, reward_network)
+    engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics)
     for level in curriculum:
         print_green(f'[Training] Training curriculum level: {level}')
         for epoch in range(epochs):
@@ -380,7 +383,7 @@ def _load_or_train(make, path, what, train):
 
 
 def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirectional, epochs, batch_size,
-                      retrain_all=False, curriculum=None):
+                      retrain_all=False, curriculum=None, chain_semantics="batch"):
     """Entry point (trainers.py:312-399): the three pre-trained networks are loaded from their
     checkpoints (or trained by their pre-training loops when a file is missing, or all of them with
     retrain_all), the reward network is frozen, Adam(lr=1e-4) runs over value + policy, the plain or
@@ -428,12 +431,13 @@ def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirecti
     save_paths = [model_save_path, network_paths["a2c_network"]]
     if curriculum is None:
         a2c_network = a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths,
-                                   batch_size, epochs)
+                                   batch_size, epochs, chain_semantics=chain_semantics)
     else:
         if 16 not in curriculum:
             curriculum.append(16)  # Final Curriculum Level, ie Full Training
         a2c_network = a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir,
-                                              save_paths, batch_size, epochs, curriculum)
+                                              save_paths, batch_size, epochs, curriculum,
+                                              chain_semantics=chain_semantics)
     with open(results_save_path, 'a') as f:
         f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
         f.write(str(a2c_network))

@@ -222,9 +222,33 @@ int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const
 /* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
 int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
                           icrl_stream_t stream);
-/* h_prev[pos, :] = h of position pos-1 (zeros for pos 0), taken from `saved` (gru = 0: the LSTM
- * chain's 6 slots per position; 1: the GRU chain's 5) */
-int icrl_chain_hprev(const float* saved, int64_t positions, int gru, float* h_prev, icrl_stream_t stream);
+/* h_prev[pos, :] = h of position pos-stride (zeros for pos < stride), taken from `saved` (gru = 0:
+ * the LSTM chain's 6 slots per position; 1: the GRU chain's 5).  stride 1: the batch-1 chains;
+ * stride N: the per-row chains below. */
+int icrl_chain_hprev(const float* saved, int64_t positions, int gru, int64_t stride, float* h_prev,
+                     icrl_stream_t stream);
+
+/* ---- per-row chains -----------------------------------------------------------
+ * ValueNetworkRNN / RewardNetworkRNN (models.py:130-135, 223-228) as the reference runs them at
+ * batch size 1, for N images at once: row i walks its own columns, call after call (the state is
+ * kept across the calls of a minibatch, trainers.py:495-496), from a zero state and independently
+ * of the other rows.  An explicit change of semantics for batches of more than one row, where the
+ * reference's recurrence runs through all rows (see icrl_lstm_chain_fwd); never a default.
+ * Arguments, per-position layouts (saved, h_emit, dgates) and workspace
+ * (icrl_chain_seg_workspace_floats(N) floats each) as for the segmented entry points with one
+ * segment per row; N <= 4096.  persistent = 1: all steps in one launch (needs
+ * icrl_chain_pair_supported(N)), 0: one launch per step; same results bit for bit.  status[0] is
+ * set to 0, or to 1 when a persistent launch gave up waiting for a peer workgroup (results are
+ * then invalid); check it after synchronising. */
+int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                             const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                             int n_calls, int persistent, float* h_emit_v, float* saved_v,
+                             float* h_emit_r, float* work_v, float* work_r, int* status,
+                             icrl_stream_t stream);
+/* BPTT of the per-row value chains: dgates[pos, 4H] from d_emit [n_calls, N, H] and `saved`. */
+int icrl_lstm_chain_bwd_rows(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                             int n_calls, int persistent, float* dgates, float* work, int* status,
+                             icrl_stream_t stream);
 
 /* ---- value head (models.py:175-178) ------------------------------------------
  * y[r,:] = yh[r,:] + u[r % N,:]  (u = W1[:, :F]*feat + b1, yh = W1[:, F:]*h_emit);

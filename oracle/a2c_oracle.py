@@ -140,35 +140,42 @@ def value_chain_positions(n, p0, n_calls, extra=0):
     return np.array(calls), np.array(cols), np.array(rows)
 
 
-def value_forward(Vp, features, tokens, p0, n_calls):
+def value_forward(Vp, features, tokens, p0, n_calls, per_sample=False):
     """values [N, n_calls] of ValueNetwork called on tokens[:, :p0+s], s = 0..n_calls-1,
-    with ONE hidden state carried through rows, columns and calls."""
+    with ONE hidden state carried through rows, columns and calls.  per_sample: what the same
+    classes compute when called with one image at a time (batch_size 1): every row carries its own
+    state through its columns and calls, from zeros."""
     n = tokens.shape[0]
     emb = Vp["valrnn.caption_embedding.weight"]
     feats = torch.as_tensor(features, dtype=emb.dtype)
     xp_tab = emb[tokens] @ Vp["valrnn.lstm.weight_ih_l0"].t() \
         + Vp["valrnn.lstm.bias_ih_l0"] + Vp["valrnn.lstm.bias_hh_l0"]  # [N, L, 4H]
     whh_t = Vp["valrnn.lstm.weight_hh_l0"].t()
-    h = torch.zeros(1, H, dtype=emb.dtype)
-    c = torch.zeros(1, H, dtype=emb.dtype)
+    rows = n if per_sample else 1
+    h = torch.zeros(rows, H, dtype=emb.dtype)
+    c = torch.zeros(rows, H, dtype=emb.dtype)
     values = []
     for s in range(n_calls):
         outs = None
         for t in range(p0 + s):
+            if per_sample:
+                h, c = _lstm_step(xp_tab[:, t], h, c, whh_t)
+                continue
             outs = []
             for i in range(n):
                 h, c = _lstm_step(xp_tab[i, t][None], h, c, whh_t)
                 outs.append(h[0])
-        hs = torch.stack(outs, 0)  # hidden outputs of the last column's N positions
+        hs = h if per_sample else torch.stack(outs, 0)  # hidden outputs of the last column's N positions
         state = torch.cat((feats, hs), dim=1)
         y = state @ Vp["linear1.weight"].t() + Vp["linear1.bias"]
         values.append((y @ Vp["linear2.weight"].t() + Vp["linear2.bias"])[:, 0])
     return torch.stack(values, 1)
 
 
-def reward_forward(Rp, features, tokens, p0, n_calls):
+def reward_forward(Rp, features, tokens, p0, n_calls, per_sample=False):
     """rewards [N, n_calls]: GetRewards on tokens[:, :p0+s+1] (the newly sampled token is
-    included, trainers.py:454-459), one GRU state carried through everything."""
+    included, trainers.py:454-459), one GRU state carried through everything (per_sample: one
+    state per row, as in value_forward)."""
     n = tokens.shape[0]
     emb = Rp["rewrnn.caption_embedding.weight"]
     feats = torch.as_tensor(features, dtype=emb.dtype)
@@ -177,16 +184,19 @@ def reward_forward(Rp, features, tokens, p0, n_calls):
     bhh = Rp["rewrnn.gru.bias_hh_l0"]
     ve = feats @ Rp["visual_embed.weight"].t() + Rp["visual_embed.bias"]
     ve = ve / ve.norm(dim=1, keepdim=True).clamp_min(1e-12)  # F.normalize, eps 1e-12
-    h = torch.zeros(1, H, dtype=emb.dtype)
+    h = torch.zeros(n if per_sample else 1, H, dtype=emb.dtype)
     rewards = []
     for s in range(n_calls):
         outs = None
         for t in range(p0 + s + 1):
+            if per_sample:
+                h = _gru_step(xp_tab[:, t], h, whh_t, bhh)
+                continue
             outs = []
             for i in range(n):
                 h = _gru_step(xp_tab[i, t][None], h, whh_t, bhh)
                 outs.append(h[0])
-        hs = torch.stack(outs, 0)
+        hs = h if per_sample else torch.stack(outs, 0)
         se = hs @ Rp["semantic_embed.weight"].t() + Rp["semantic_embed.bias"]
         se = se / se.norm(dim=1, keepdim=True).clamp_min(1e-12)
         rewards.append((ve * se).sum(dim=1))
@@ -202,14 +212,16 @@ def a2c_loss(values, rewards, log_probs):
 
 
 def a2c_step(policy, value, reward, features, captions, uniforms=None, level=None,
-             forced_tokens=None, dtype=torch.float64, want_grads=True):
+             forced_tokens=None, dtype=torch.float64, want_grads=True, per_sample=False):
     """One A2C minibatch: rollout, rewards, loss and gradients (no optimizer step).
 
     level=None is a2c_training (trainers.py:436-480): start from captions[:, :1],
     caplen-1 steps.  level=k is a2c_curriculum_training (trainers.py:547-594): start
     from captions[:, :caplen-k], k steps; returns None when caplen-k < 1.
     uniforms: flat array consumed in (step, row) order.  forced_tokens [N, p0+steps]
-    replaces sampling (teacher forcing on the reference's own tokens).
+    replaces sampling (teacher forcing on the reference's own tokens).  per_sample: every row
+    owns its value / reward recurrent state; the result then equals the mean over rows of the
+    reference's minibatches of one image each.
     """
     captions = np.asarray(captions)
     n = captions.shape[0]
@@ -230,9 +242,9 @@ def a2c_step(policy, value, reward, features, captions, uniforms=None, level=Non
     else:
         u = np.asarray(uniforms)[:n_steps * n].reshape(n_steps, n)
         tokens, logits, logp = policy_rollout(P, features, prefix, n_steps, uniforms=u)
-    values = value_forward(Vp, features, tokens, p0, n_steps)
+    values = value_forward(Vp, features, tokens, p0, n_steps, per_sample)
     with torch.no_grad():
-        rewards = reward_forward(Rp, features, tokens, p0, n_steps)
+        rewards = reward_forward(Rp, features, tokens, p0, n_steps, per_sample)
     loss, actor, critic, adv = a2c_loss(values, rewards, logp)
     out = {
         "tokens": tokens.numpy(), "logits": logits.detach().numpy(),

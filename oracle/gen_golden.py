@@ -11,7 +11,7 @@ empty placeholder modules are registered for those names; the tensorboard
 placeholder's SummaryWriter records the (tag, value, step) triples, which are the
 reference's per-minibatch outputs (trainers.py:489-492).
 
-Usage:  python oracle/gen_golden.py [--lookahead-only | --pretrain-only]           (writes tests/golden/)
+Usage:  python oracle/gen_golden.py [--lookahead-only | --pretrain-only | --per-sample-only]           (writes tests/golden/)
 """
 import importlib
 import os
@@ -238,6 +238,79 @@ def golden_lookahead(models, trainers, cfg):
             "logit_margin": np.float64(want["logit_margin"]), "score_margin": np.float64(want["score_margin"])}
 
 
+class _GradRecorder(torch.optim.Optimizer):
+    """Stands in for Adam in the reference's loop: step() adds the minibatch's gradients to a running
+    sum and leaves the parameters alone, so that every minibatch is evaluated at the same parameters."""
+
+    def __init__(self, named_params):
+        self.names = [k for k, _ in named_params]
+        super().__init__([p for _, p in named_params], {})
+        self.sums, self.count = {}, 0
+
+    def step(self, closure=None):
+        for name, p in zip(self.names, self.param_groups[0]["params"]):
+            if p.grad is not None:
+                self.sums[name] = self.sums.get(name, 0) + p.grad.detach().double().clone()
+        self.count += 1
+
+
+def golden_per_sample(models, trainers, cfg):
+    """The reference's a2c_training (trainers.py:402-500) with batch_size 1 over n images: each image is
+    a minibatch of its own, so its value / reward recurrences start from zeros and see only its own
+    prefixes.  Stored: the visiting order, per image tokens / values / rewards / logged scalars, and the
+    mean over images of the gradients (all images evaluated at the same parameters)."""
+    n, vocab, caplen, fdim, seed = cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"]
+    pol, val, rew = build_nets(models, vocab, fdim, seed)
+    rew.requires_grad_(False)
+    rew.train(False)
+    a2c = models.AdvantageActorCriticNetwork(val, pol)
+    a2c.train(True)
+    opt = _GradRecorder(list(a2c.named_parameters()))
+    data = synthetic.make_train_data(n, vocab, caplen, fdim, seed)
+    # as torch tensors: a NumPy array indexed by the one-element permutation slice of a batch of one
+    # (utilities.py:172-175) would lose its batch dimension
+    for k in ("train_captions", "train_image_idxs", "train_features"):
+        data[k] = torch.as_tensor(np.asarray(data[k]))
+    rec = {"values": [], "rewards": [], "tokens": [], "batches": []}
+    hook = a2c.register_forward_hook(lambda m, i, o: rec["values"].append(o[0].detach().clone()))
+    orig_rewards, orig_batches = trainers.GetRewards, trainers.get_coco_minibatches
+
+    def rewards_spy(features, captions, reward_network):
+        r = orig_rewards(features, captions, reward_network)
+        rec["rewards"].append(r.detach().clone())
+        rec["tokens"].append(captions.detach().clone())
+        return r
+
+    def batches_spy(d, batch_size=100, split="train"):
+        for caps, feats, urls in orig_batches(d, batch_size=batch_size, split=split):
+            rec["batches"].append((np.array(caps), np.array(feats)))
+            yield caps, feats, urls
+
+    trainers.GetRewards, trainers.get_coco_minibatches = rewards_spy, batches_spy
+    trainers.save_a2c_model = lambda *a, **k: None
+    del SCALARS[:]
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    try:
+        trainers.a2c_training(data, a2c, rew, opt, "/tmp/plots", [], 1, 1)
+    finally:
+        hook.remove()
+        trainers.GetRewards, trainers.get_coco_minibatches = orig_rewards, orig_batches
+    steps = caplen - 1
+    assert opt.count == n and len(rec["batches"]) == n and len(rec["values"]) == n * steps
+    out = {"cfg": np.array([n, vocab, caplen, fdim, seed]),
+           "captions": np.concatenate([b[0] for b in rec["batches"]]).astype(np.int64),
+           "features": np.concatenate([b[1] for b in rec["batches"]]).astype(np.float32),
+           # the reference drew image after image: uniform k of image i is draw i*steps + k
+           "uniforms": synthetic.make_uniforms(seed, steps * n).reshape(n, steps).T.copy(),
+           "tokens": np.concatenate([rec["tokens"][i * steps + steps - 1].numpy() for i in range(n)]).astype(np.int64),
+           "values": np.stack([torch.cat(rec["values"][i * steps:(i + 1) * steps], 1).numpy()[0] for i in range(n)]),
+           "rewards": np.stack([torch.cat(rec["rewards"][i * steps:(i + 1) * steps], 1).numpy()[0] for i in range(n)]),
+           "scalars": np.array([s[1] for s in SCALARS]).reshape(n, 3)}
+    summarize("grad", {k: v / opt.count for k, v in opt.sums.items()}, out)
+    return out
+
+
 def _seeded_factory(models, kind, vocab, fdim, seed):
     """A stand-in for the reference's constructor call inside its training loops: builds the
     reference class, then overwrites its fresh parameters with the seeded recipe's."""
@@ -340,6 +413,13 @@ def main():
     models, trainers = import_reference()
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
+    if "--per-sample-only" in sys.argv:
+        for cfg in (dict(name="n6_v100_l10_f512_s0", n=6, vocab=100, caplen=10, fdim=512, seed=0),
+                    dict(name="n5_v257_l12_f2048_s1", n=5, vocab=257, caplen=12, fdim=2048, seed=1)):
+            out = golden_per_sample(models, trainers, cfg)
+            np.savez_compressed(os.path.join(gdir, "per_sample_%s.npz" % cfg["name"]), **out)
+            print("wrote per-sample", cfg["name"], "losses", out["scalars"][:, 0])
+        return
     if "--pretrain-only" in sys.argv:
         import tempfile
         cfg = dict(name="n6_v100_f512_s1", n=6, vocab=100, fdim=512, seed=1)

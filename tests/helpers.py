@@ -36,6 +36,8 @@ def load_lookahead(name):
 
 
 GOLDEN_PRETRAIN = "pretrain_n6_v100_f512_s1"
+# the reference's a2c_training run with one image per minibatch (every image its own recurrent state)
+GOLDEN_PER_SAMPLE = ["per_sample_n6_v100_l10_f512_s0", "per_sample_n5_v257_l12_f2048_s1"]
 
 
 def _hash_name(name):

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, GOLDEN_PRETRAIN, check_summary, load_golden, load_lookahead,
+from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, GOLDEN_PER_SAMPLE, GOLDEN_PRETRAIN, check_summary, load_golden, load_lookahead,
                      params_for, synthetic)
 from oracle import a2c_oracle as orc
 
@@ -315,6 +315,68 @@ def test_step_matches_float64_oracle_full_gradients(n, vocab, caplen, fdim):
             got = mod[prefix + k].grad.cpu().numpy().astype(np.float64)
             scale = np.sqrt((gw ** 2).mean()) + 1e-12
             assert np.abs(got - gw).max() <= 2e-3 * scale + 1e-7, (k, np.abs(got - gw).max(), scale)
+
+
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("name", GOLDEN_PER_SAMPLE)
+def test_per_sample_chains_match_reference_at_batch_size_one(name, persistent):
+    """chain_semantics="per_sample" on a batch against the reference's own loop fed one image per
+    minibatch: the same tokens from the same draws, per-image values and rewards, the mean of the logged
+    per-image scalars and the mean of the per-image gradients."""
+    g = load_lookahead(name)
+    cfg = g["cfg"]
+    n, steps = cfg["n"], cfg["caplen"] - 1
+    a2c, rew = build_modules(cfg)
+    engine = trainers.build_engine(a2c, rew, chain_semantics="per_sample", persistent=persistent)
+    feats = torch.from_numpy(g["features"]).cuda()
+    prefix = torch.from_numpy(g["captions"][:, :1]).cuda()
+    res = engine.step(feats, prefix, steps, uniforms=torch.from_numpy(g["uniforms"].reshape(-1)).cuda()).check()
+    assert res.chain_plan == (("rows",), ("rows",))
+    assert np.array_equal(res.tokens.cpu().numpy(), g["tokens"])
+    np.testing.assert_allclose(res.values.cpu().numpy(), g["values"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.rewards.cpu().numpy(), g["rewards"], rtol=RTOL, atol=ATOL)
+    loss, mean_reward, mean_adv = g["scalars"].mean(axis=0)
+    sc = res.scalars.cpu().numpy()
+    assert abs(sc[0] - loss) <= RTOL * abs(loss) + 2e-6
+    assert abs(sc[3] - mean_reward) <= RTOL * abs(mean_reward) + 2e-6
+    assert abs(sc[4] - mean_adv) <= RTOL * abs(mean_adv) + 2e-6
+    for k, p in a2c.named_parameters():
+        check_summary(g, "grad", k, p.grad.cpu().numpy(), 2e-3, 1e-7)
+
+
+@pytest.mark.parametrize("n,vocab,caplen,fdim", [(70, 300, 9, 2048), (1, 50, 5, 512)])
+def test_per_sample_step_matches_float64_oracle_and_both_launch_modes_agree(n, vocab, caplen, fdim):
+    """Per-row chains on a batch that is not a multiple of the 32-row tiles (and on a single row, where
+    both semantics coincide): every output and gradient against the float64 oracle; the persistent
+    launches and the launch-per-step kernels give the same values and rewards bit for bit."""
+    cfg = dict(n=n, vocab=vocab, caplen=caplen, fdim=fdim, seed=7, level=None)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(n, vocab, caplen, fdim, 7)
+    steps = caplen - 1
+    u = synthetic.make_uniforms(7, steps * n)
+    _, res, grads = _step_with(a2c, rew, feats, caps, steps, u, chain_semantics="per_sample")
+    _, res2, grads2 = _step_with(a2c, rew, feats, caps, steps, u, chain_semantics="per_sample", persistent=False)
+    assert torch.equal(res.tokens, res2.tokens) and torch.equal(res.values, res2.values)
+    assert torch.equal(res.rewards, res2.rewards)
+    for k in grads:   # the chains' outputs are bit-identical; some reductions behind them add with atomics
+        assert (grads[k] - grads2[k]).abs().max().item() <= 1e-5 * grads[k].abs().max().item() + 1e-12, k
+    toks = res.tokens.cpu().numpy()
+    pol, val, rw = params_for(cfg)
+    want = orc.a2c_step(pol, val, rw, feats, caps, forced_tokens=toks, per_sample=True)
+    np.testing.assert_allclose(res.values.cpu().numpy(), want["values"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.rewards.cpu().numpy(), want["rewards"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.scalars.cpu().numpy()[:5], [want["loss"], want["actor_loss"], want["critic_loss"],
+                                                               want["mean_reward"], want["mean_advantage"]],
+                               rtol=RTOL, atol=2e-6)
+    for prefix, wg in (("policy_network.", want["policy_grads"]), ("value_network.", want["value_grads"])):
+        for k, gw in wg.items():
+            got = grads[prefix + k].cpu().numpy().astype(np.float64)
+            scale = np.sqrt((gw ** 2).mean()) + 1e-12
+            assert np.abs(got - gw).max() <= 2e-3 * scale + 1e-7, (k, np.abs(got - gw).max(), scale)
+    if n == 1:   # one row: the reference's batch-1 chain IS the per-row chain
+        _, exact, g_exact = _step_with(a2c, rew, feats, caps, steps, u, chain_mode="exact")
+        np.testing.assert_allclose(exact.values.cpu().numpy(), res.values.cpu().numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(exact.rewards.cpu().numpy(), res.rewards.cpu().numpy(), rtol=1e-5, atol=2e-6)
 
 
 def test_module_forwards_carry_hidden_state_like_the_reference():

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, GOLDEN_PRETRAIN, check_summary, load_golden, load_lookahead,
+from helpers import (GOLDEN_A2C, GOLDEN_CURRICULUM, GOLDEN_LOOKAHEAD, GOLDEN_PER_SAMPLE, GOLDEN_PRETRAIN, check_summary, load_golden, load_lookahead,
                      params_for, synthetic)
 from oracle import a2c_oracle as orc
 
@@ -145,6 +145,35 @@ def test_pretraining_steps_match_reference():
         rew = orc.adam_update(rew, grads, state, lr=1e-4)
     for k, v in rew.items():
         check_summary(g, "reward_after", k, v, 1e-5, 2e-6)
+
+
+@pytest.mark.parametrize("name", GOLDEN_PER_SAMPLE)
+def test_per_sample_chains_match_reference_at_batch_size_one(name):
+    """per_sample=True on a batch == the reference's loop fed one image per minibatch: same tokens from
+    the same draws, per-image values / rewards / logged scalars, and the mean of the per-image gradients."""
+    g = load_lookahead(name)
+    cfg = g["cfg"]
+    pol, val, rew = params_for(cfg)
+    steps = cfg["caplen"] - 1
+    free = orc.a2c_step(pol, val, rew, g["features"], g["captions"], uniforms=g["uniforms"].reshape(-1),
+                        want_grads=False, per_sample=True)
+    assert np.array_equal(free["tokens"], g["tokens"])
+    out = orc.a2c_step(pol, val, rew, g["features"], g["captions"], forced_tokens=g["tokens"], per_sample=True)
+    np.testing.assert_allclose(out["values"], g["values"], rtol=RTOL, atol=2e-5)
+    np.testing.assert_allclose(out["rewards"], g["rewards"], rtol=RTOL, atol=2e-5)
+    loss, mean_reward, mean_adv = g["scalars"].mean(axis=0)   # equal caption lengths: mean of per-image means
+    assert abs(out["loss"] - loss) <= RTOL * abs(loss) + 2e-6
+    assert abs(out["mean_reward"] - mean_reward) <= RTOL * abs(mean_reward) + 2e-6
+    assert abs(out["mean_advantage"] - mean_adv) <= RTOL * abs(mean_adv) + 2e-6
+    for k, grad in out["policy_grads"].items():
+        check_summary(g, "grad", "policy_network." + k, grad, 1e-3, 1e-7)
+    for k, grad in out["value_grads"].items():
+        check_summary(g, "grad", "value_network." + k, grad, 1e-3, 1e-7)
+    # and it is a different computation from the batch-1 chain through all rows
+    batch = orc.a2c_step(pol, val, rew, g["features"], g["captions"], forced_tokens=g["tokens"], want_grads=False)
+    assert np.abs(batch["values"][1:] - out["values"][1:]).max() > 1e-3
+    np.testing.assert_allclose(batch["values"][0, 0], out["values"][0, 0], rtol=1e-12)
+    assert steps == out["n_steps"]
 
 
 def test_curriculum_skips_short_captions():
