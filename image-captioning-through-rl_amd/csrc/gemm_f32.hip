@@ -31,7 +31,7 @@ struct GemmArgs {
     const float* bias; const float* bias2;
     int accumulate;
     int a_vec, b_vec;  // 1 = 16-byte loads are aligned for this operand
-    int kchunk;        // k-range per blockIdx.y (split-K); a multiple of BK
+    int kchunk;        // k-range per split (split-K); a multiple of BK
     int64_t slab;      // C offset (floats) between split-K partial results
 };
 
@@ -144,16 +144,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
-    // XCD-aware tile order: consecutive tiles of one output row-panel share A rows, so
-    // give each XCD (blocks b, b+8, ... share one) a contiguous run of tiles.
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (round-robin dispatch of a 1-D grid), and each
+    // XCD has its own L2.  Every XCD gets one contiguous run of the sequence (split, tile).  The tiles
+    // of a split are sequenced so that a run covers ALL tiles along the dimension of the smaller operand
+    // and a slice of the other (M < N: all tile-rows, a range of tile-columns: the XCD reads all of A
+    // and 1/8 of B), in bands 8 tiles wide that are walked in 8 x 8 blocks; inside a block the fast
+    // index is the one whose tiles share a panel of the LARGER operand, so that the workgroups
+    // launched back to back - which then run in step - fetch that panel once.
+    constexpr int BAND = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int split = bid / tiles;
+    const int id = bid - split * tiles;
+    int mt, nt;
+    {
+        const bool m_fast = g.M < g.N;
+        const int tf = m_fast ? tiles_m : tiles_n, ts = m_fast ? tiles_n : tiles_m;
+        const int b = id / (tf * BAND), r = id - b * tf * BAND;      // band along the slow dimension
+        const int w = min(BAND, ts - b * BAND);
+        const int c = r / (BAND * w), r2 = r - c * BAND * w;         // block along the fast dimension
+        const int hc = min(BAND, tf - c * BAND);
+        const int s_in = r2 / hc, f_in = r2 - s_in * hc;
+        const int f = c * BAND + f_in, sl = b * BAND + s_in;
+        mt = m_fast ? f : sl;
+        nt = m_fast ? sl : f;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -164,11 +185,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 32], rb[BN / 32];
-    // split-K: blockIdx.y owns k in [kbeg, kend) and writes its own partial slab
-    const int kbeg = blockIdx.y * g.kchunk;
+    // split-K: split s owns k in [kbeg, kend) and writes its own partial slab
+    const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
-    float* const Cout = g.C + (int64_t)blockIdx.y * g.slab;
+    float* const Cout = g.C + (int64_t)split * g.slab;
     const int nk_full = (kend - kbeg) / BK;  // stages that lie wholly inside the k range
     const bool fast_a = g.a_vec && m0 + BM <= g.M, fast_b = g.b_vec && n0 + BN <= g.N;
     const float* pa[BM / 32];
@@ -226,8 +247,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int col = n0 + wc * (BN / 2) + j * 32 + l31;
             if (col >= g.N) continue;
             float badd = 0.f;
-            if (g.bias && blockIdx.y == 0) badd += g.bias[col];
-            if (g.bias2 && blockIdx.y == 0) badd += g.bias2[col];
+            if (g.bias && split == 0) badd += g.bias[col];
+            if (g.bias2 && split == 0) badd += g.bias2[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wr * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 template <int BM, int BN>
 int launch(const GemmArgs& g, int a_km, int b_km, int splits, hipStream_t st) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    dim3 grid(tiles, splits), block(256);
+    dim3 grid(tiles * splits), block(256);
     if (!a_km && !b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, st, g);
     else if (!a_km && b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, st, g);
     else if (a_km && !b_km) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, st, g);
