@@ -152,8 +152,9 @@ def main():
     # [segments, 512] x [512, G*512] product; the chain events above time those launches
     seg_flops = 0.0
     plan_fwd, plan_bwd = res.chain_plan
+    plan_rew = res.reward_plan
     flops_of = {}
-    for kind, gates, p0, plan in (("lstm_chain_fwd", 4, 1, plan_fwd), ("gru_chain_fwd", 3, 2, plan_fwd),
+    for kind, gates, p0, plan in (("lstm_chain_fwd", 4, 1, plan_fwd), ("gru_chain_fwd", 3, 2, plan_rew),
                                   ("lstm_chain_bwd", 4, 1, plan_bwd)):
         if plan[0] == "segmented":
             _, segs, warm = plan
@@ -161,7 +162,7 @@ def main():
             launches = warm + (positions + segs - 1) // segs
             flops_of[kind] = launches * 2.0 * segs * 512 * gates * 512
             seg_flops += flops_of[kind]
-    if "lstm_chain_fwd" in flops_of:
+    if "lstm_chain_fwd" in flops_of and "gru_chain_fwd" in flops_of:
         flops_of["chain_pair_fwd"] = flops_of["lstm_chain_fwd"] + flops_of["gru_chain_fwd"]
     for kind, entry in chains.items():
         if kind in flops_of:   # the segment-parallel kernels are f32 MFMA kernels: price them like the GEMM
@@ -202,7 +203,8 @@ def main():
                 "policy_flops_per_image_fwd_bwd": policy_flops_per_image,
                 "achieved_tflops": policy_flops_per_image * value / world / 1e12,
                 "frac_of_f32_mfma_peak": policy_flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS},
-            "chain_plan": {"forward": list(plan_fwd), "backward": list(plan_bwd)}, "seam_check": engine.last_seam,
+            "chain_plan": {"forward": list(plan_fwd), "reward_forward": list(plan_rew), "backward": list(plan_bwd)},
+            "seam_check": engine.last_seam,
             "seam_fallbacks_in_run": engine.fallbacks, "last_loss": float(res.scalars[0]),
         }
         if world == 1 and not args.no_cpu_baseline and args.chain_semantics == "batch":

@@ -1100,12 +1100,12 @@ extern "C" int icrl_chain_pair_supported(int segments) {
 
 extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
                                        const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
-                                       int n_calls, int segments, int warmup, float* h_emit_v, float* saved_v,
-                                       float* h_emit_r, float* work_v, float* work_r, float* seam_err_v,
-                                       float* seam_err_r, icrl_stream_t stream) {
+                                       int n_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
+                                       float* saved_v, float* h_emit_r, float* work_v, float* work_r,
+                                       float* seam_err_v, float* seam_err_r, icrl_stream_t stream) {
     ChainArgs v, r;
-    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_v, n_calls, segments, warmup, v.g)) return rc;
-    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_r, n_calls, segments, warmup, r.g)) return rc;
+    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_v, n_calls, segments, warmup_v, v.g)) return rc;
+    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_r, n_calls, segments, warmup_r, r.g)) return rc;
     ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r &&
                  seam_err_v && seam_err_r, "icrl_chain_pair_fwd_seg: null pointer");
     ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(xproj_r) && aligned16(w_hh_r) &&

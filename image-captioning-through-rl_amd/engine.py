@@ -45,10 +45,12 @@ class A2CStepResult:
     """Device tensors of one minibatch.  tokens [N, p0+S] int64; log_probs, values,
     rewards [N, S] float32; scalars[0..4] = loss, actor, critic, mean reward, mean adv."""
 
-    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status, chain_plan=None):
+    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status, chain_plan=None, reward_plan=None):
         self.tokens, self.log_probs, self.values, self.rewards = tokens, log_probs, values, rewards
         self.scalars, self.entropy, self.status = scalars, entropy, status
-        self.chain_plan = chain_plan  # ("exact",) or ("segmented", segments, warmup) that produced it
+        # (value chain forward, value chain backward), each ("exact",), ("segmented", segments, warmup) or ("rows",)
+        self.chain_plan = chain_plan
+        self.reward_plan = reward_plan  # the same for the reward chain (forward only)
 
     def check(self):
         """Synchronises; raises if a chain kernel gave up waiting for a peer workgroup."""
@@ -59,34 +61,53 @@ class A2CStepResult:
 
 
 class _WarmupLadder:
-    """Where one direction (forward / backward chains) starts in the warm-up ladder.  It moves up when a
-    length is rejected, or accepted with less than 3x margin (before it can fail: the parameters drift
-    slowly from minibatch to minibatch); it probes one rung down after eight accepted minibatches whose
-    seam error sat at the rounding floor (less than 6 % of the tolerance), and a probe that does not hold
-    is not repeated for a while (32 minibatches, doubling up to 1024)."""
+    """Where one chain (value forward, reward forward, value backward) starts in the warm-up ladder.
 
-    def __init__(self):
-        self.first, self.calm, self.cooldown, self.penalty, self.probing = 0, 0, 0, 32, False
+    Up: when a length is rejected; and before that can happen, when the seam error (as a fraction of
+    its tolerance) is above one half, or would pass 1 within two more minibatches at the rate it has
+    been growing from minibatch to minibatch at a fixed length (the parameters drift slowly, and while a
+    network's memory is getting longer the error at a fixed length grows by a steady factor per update).
+    Down: the error falls geometrically with the warm-up length until only rounding is left, at about a
+    tenth of the tolerance; after enough accepted minibatches in a row at that floor (under 15 %) the
+    next one probes one rung down.  A failed probe costs a redone minibatch and a successful one saves
+    the rung's steps on every later minibatch, so short rungs wait longer (6 / 24 / 64 minibatches for
+    rungs of >= 64 / >= 32 / fewer steps), and a probe that does not hold is not repeated for a while
+    (32 minibatches, doubling up to 1024)."""
+
+    def __init__(self, warmups, first=0):
+        self.warmups = tuple(warmups)
+        self.first, self.calm, self.cooldown, self.penalty, self.probing = first, 0, 0, 32, False
+        self.prev, self.growth = None, 1.0
+
+    def _calm_needed(self):
+        if self.first == 0 or self.first >= len(self.warmups):
+            return 6
+        gain = self.warmups[self.first] - self.warmups[self.first - 1]
+        return 6 if gain >= 64 else 24 if gain >= 32 else 64
 
     def accepted(self, idx, checks, last):
         if idx != self.first or not checks:
             return
         worst = max(e / t if t > 0 else float("inf") for e, t in checks)
+        if self.prev is not None and self.prev[0] == idx and self.prev[1] > 0.1:
+            self.growth = 0.5 * self.growth + 0.5 * min(max(worst / self.prev[1], 0.5), 3.0)
+        self.prev = (idx, worst)
+        ahead = max(1.0, self.growth) ** 2
         self.cooldown = max(0, self.cooldown - 1)
-        if worst > 0.3:
+        if worst > 0.5 or worst * ahead > 1.0:
             self.first, self.calm = min(idx + 1, last), 0
             if self.probing:
                 self._probe_failed()
         else:
             self.probing = False
-            self.calm = self.calm + 1 if worst < 0.06 else 0
-            if self.calm >= 8 and self.cooldown == 0 and self.first > 0:
+            self.calm = self.calm + 1 if worst < 0.15 else 0
+            if self.calm >= self._calm_needed() and self.cooldown == 0 and self.first > 0:
                 self.first, self.calm, self.probing = self.first - 1, 0, True
 
     def rejected(self, new_idx):
         if self.probing:
             self._probe_failed()
-        self.first, self.calm = new_idx, 0
+        self.first, self.calm, self.prev = new_idx, 0, None
 
     def _probe_failed(self):
         self.probing, self.cooldown, self.penalty = False, self.penalty, min(2 * self.penalty, 1024)
@@ -100,7 +121,8 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch",
-                 warmups=(96, 128, 160, 192, 256, 320, 384, 512, 768, 1024, 1536, 2048)):
+                 warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
+                          1536, 2048), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
         missing from the grads dicts (e.g. frozen pretrained embeddings) get no gradient."""
@@ -115,7 +137,10 @@ class A2CEngine:
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
-        self._ladder_fwd, self._ladder_bwd = _WarmupLadder(), _WarmupLadder()
+        # every chain starts at the first rung of at least first_warmup steps (freshly initialised networks
+        # pass there); shorter rungs are reached only by probing down
+        start = next((i for i, w in enumerate(self.warmups) if w >= first_warmup), len(self.warmups) - 1)
+        self._ladder_fv, self._ladder_fr, self._ladder_bwd = (_WarmupLadder(self.warmups, start) for _ in range(3))
         self.last_seam = None
         self._ws = {}
         self._side = None
@@ -215,7 +240,7 @@ class A2CEngine:
     @staticmethod
     def _next_plan(plans, attempt, checks):
         """After a rejected attempt: the seam error shrinks geometrically with the warm-up length
-        (from an O(1) initial mismatch), so estimate the length that reaches a tenth of the
+        (from an O(1) initial mismatch), so estimate the length that reaches a quarter of the
         tolerance and jump to the first plan at least that long.  checks: [(error, tolerance)]."""
         import math
         w = plans[attempt][2]
@@ -224,7 +249,7 @@ class A2CEngine:
             if err > tol and tol <= 0:
                 return len(plans) - 1
             if err > tol and 0 < err < 0.5:
-                need = max(need, int(math.ceil(w * math.log(tol / 10.0) / math.log(err))))
+                need = max(need, int(math.ceil(w * math.log(tol / 4.0) / math.log(err))))
             elif err >= 0.5 or err != err:
                 need = max(need, 4 * w)
         for idx in range(attempt + 1, len(plans)):
@@ -401,52 +426,57 @@ class A2CEngine:
         side = self._side_stream() if self.concurrent else main
         plans = self._plans(ws)
         last = len(plans) - 1
-        fi, bi = min(self._ladder_fwd.first, last), min(self._ladder_bwd.first, last)
+        fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
         redo_forward = True
         while True:
-            pf, pb = plans[fi], plans[bi]
+            pv, pr, pb = plans[fv], plans[fr], plans[bi]
             if redo_forward:
-                self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, pf, pb)
+                self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, pv, pr, pb)
             else:  # only the value chain's BPTT was rejected: everything before it stands
                 self._value_chain_backward(ws, n, p0, s, main, side, pb, None)
                 self._mark("backward_done")
-            seg_f, seg_b = pf[0] == "segmented", with_bwd and pb[0] == "segmented"
-            if not (seg_f or seg_b):
+            seg_v, seg_r, seg_b = pv[0] == "segmented", pr[0] == "segmented", with_bwd and pb[0] == "segmented"
+            if not (seg_v or seg_r or seg_b):
                 break
             seam = ws["seam"].tolist()  # host sync; the caller synchronises per step anyway
             self.last_seam = seam
-            fwd_checks = [(seam[0], self.SEAM_TOL_FWD), (seam[2], self.SEAM_TOL_FWD)] if seg_f else []
-            bwd_checks = [(seam[4] / seam[5] if seam[5] > 0 else 0.0, self.SEAM_TOL_BWD)] if seg_b else []
-            ok_f = all(e <= t for e, t in fwd_checks)
-            ok_b = all(e <= t for e, t in bwd_checks)
-            if ok_f and ok_b:
-                self._ladder_fwd.accepted(fi, fwd_checks, last)
-                self._ladder_bwd.accepted(bi, bwd_checks, last)
+            checks_v = [(seam[0], self.SEAM_TOL_FWD)] if seg_v else []
+            checks_r = [(seam[2], self.SEAM_TOL_FWD)] if seg_r else []
+            checks_b = [(seam[4] / seam[5] if seam[5] > 0 else 0.0, self.SEAM_TOL_BWD)] if seg_b else []
+            ok_v, ok_r, ok_b = (all(e <= t for e, t in c) for c in (checks_v, checks_r, checks_b))
+            if ok_v and ok_r and ok_b:
+                self._ladder_fv.accepted(fv, checks_v, last)
+                self._ladder_fr.accepted(fr, checks_r, last)
+                self._ladder_bwd.accepted(bi, checks_b, last)
                 break
             self.fallbacks += 1
-            redo_forward = not ok_f
-            if not ok_f:
-                fi = self._next_plan(plans, fi, fwd_checks)
-                self._ladder_fwd.rejected(fi)
+            redo_forward = not (ok_v and ok_r)
+            if not ok_v:
+                fv = self._next_plan(plans, fv, checks_v)
+                self._ladder_fv.rejected(fv)
+            if not ok_r:
+                fr = self._next_plan(plans, fr, checks_r)
+                self._ladder_fr.rejected(fr)
             if not ok_b:
-                bi = self._next_plan(plans, bi, bwd_checks)
+                bi = self._next_plan(plans, bi, checks_b)
                 self._ladder_bwd.rejected(bi)
         return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                              ws["rewards"].view(s, n).t().contiguous(), ws["scalars"],
                              ws["entropy"] if self.want_entropy else None, ws["status"],
-                             (pf, pb))
+                             (pv, pb), pr)
 
-    def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan, plan_bwd):
+    def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan, plan_r, plan_bwd):
+        """plan / plan_r: how the value / reward chain runs forward; plan_bwd: the value chain's BPTT."""
         P, V, R = self.P, self.V, self.R
         t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
         tok_flat = ws["tokT"].view(-1)
-        seg, rows = plan[0] == "segmented", plan[0] == "rows"
+        seg, seg_r, rows = plan[0] == "segmented", plan_r[0] == "segmented", plan[0] == "rows"
 
         # ---- 2. the two forward chains: one persistent launch for both when the device can hold it,
         # else the reward GRU chain on the side stream beside the value LSTM chain on the main stream
         # (per-row chains: always one call for both, persistent or a launch per step)
-        pair = rows or (seg and self.persistent and hip.chain_pair_supported(plan[1]))
+        pair = rows or (seg and seg_r and self.persistent and hip.chain_pair_supported(plan[1]))
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
@@ -457,9 +487,9 @@ class A2CEngine:
                 hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
                 ev_xpr = torch.cuda.Event()
                 ev_xpr.record(side)
-            elif seg:
+            elif seg_r:
                 hip.gru_chain_fwd_seg(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
-                                      plan[1], plan[2], ws["hr"], ws["work_r"], ws["seam"][2:4])
+                                      plan_r[1], plan_r[2], ws["hr"], ws["work_r"], ws["seam"][2:4])
             else:
                 hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                   ws["hr"], ws["sync_r"], ws["status"][1:2])
@@ -481,7 +511,7 @@ class A2CEngine:
             hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
                                    R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
                                    ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
-                                   ws["seam"][0:2], ws["seam"][2:4])
+                                   ws["seam"][0:2], ws["seam"][2:4], warmup_r=plan_r[2])
         if pair:
             ev_pair = torch.cuda.Event()
             ev_pair.record(main)

@@ -31,7 +31,7 @@ SIGNATURES = {
     "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 6 + [c_vp] * 8),
+    "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 7 + [c_vp] * 8),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
     "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -415,12 +415,14 @@ def chain_pair_supported(segments):
 
 
 def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, segments, warmup, h_emit_v,
-                       saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r):
-    """Value LSTM chain and reward GRU chain, every step, in one persistent launch."""
+                       saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r, warmup_r=None):
+    """Value LSTM chain and reward GRU chain, every step, in one persistent launch (warmup_r: the
+    reward chain's own warm-up length; default: the value chain's)."""
     with _Timed("chain_pair_fwd", chain_positions(n, p0_v, n_calls) + chain_positions(n, p0_r, n_calls)):
         rc = load().icrl_chain_pair_fwd_seg(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
                                             _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls,
-                                            segments, warmup, _ptr(_f32c(h_emit_v)), _ptr(saved_v),
+                                            segments, warmup, warmup if warmup_r is None else warmup_r,
+                                            _ptr(_f32c(h_emit_v)), _ptr(saved_v),
                                             _ptr(_f32c(h_emit_r)), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
                                             _ptr(seam_err_v), _ptr(seam_err_r), _stream())
     _check(rc, "icrl_chain_pair_fwd_seg")

@@ -197,7 +197,8 @@ int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* 
 
 /* Both forward chains of one minibatch (value LSTM: models.py:133, 140-143; reward GRU:
  * models.py:226, 231-233) in ONE persistent launch: same results as icrl_lstm_chain_fwd_seg
- * followed by icrl_gru_chain_fwd_seg with the same segments / warmup, bit for bit, without a
+ * followed by icrl_gru_chain_fwd_seg with the same segments and warmup_v / warmup_r (each chain
+ * has its own warm-up length: the two networks forget at different rates), bit for bit, without a
  * kernel boundary per step.  Its workgroups (16 per 32 segments) hand the hidden state to each
  * other inside the launch and must all be resident: icrl_chain_pair_supported(segments) says
  * whether the current device has enough CUs, and the call fails otherwise.  p0_v / p0_r =
@@ -208,9 +209,9 @@ int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* 
 int icrl_chain_pair_supported(int segments);
 int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
                             const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
-                            int n_calls, int segments, int warmup, float* h_emit_v, float* saved_v,
-                            float* h_emit_r, float* work_v, float* work_r, float* seam_err_v,
-                            float* seam_err_r, icrl_stream_t stream);
+                            int n_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
+                            float* saved_v, float* h_emit_r, float* work_v, float* work_r,
+                            float* seam_err_v, float* seam_err_r, icrl_stream_t stream);
 
 /* icrl_lstm_chain_bwd_seg (the BPTT of models.py:140-143's recurrence) as ONE persistent
  * launch: same arguments, same results bit for bit, no kernel boundary per step.  Needs

@@ -348,13 +348,14 @@ def test_persistent_chains_equal_the_per_step_launches(n, p0, calls, segs, warm)
     h_s, saved_s = torch.zeros(calls, n, H, device="cuda"), torch.zeros(pos_v, 6, H, device="cuda")
     g_s = torch.zeros(calls, n, H, device="cuda")
     hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_s, saved_s, work_v, err_v)
-    hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm, g_s, work_r, err_r)
+    warm_r = warm + 5   # each chain has its own warm-up length
+    hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm_r, g_s, work_r, err_r)
     torch.cuda.synchronize()
     ref_err = (err_v[0].item(), err_r[0].item())
     for _ in range(2):
         h_p, saved_p, g_p = torch.zeros_like(h_s), torch.zeros_like(saved_s), torch.zeros_like(g_s)
         hip.chain_pair_fwd_seg(xv, wv, xg, wg, bg, n, p0, p0 + 1, calls, segs, warm, h_p, saved_p, g_p, work_v, work_r,
-                               err_v, err_r)
+                               err_v, err_r, warmup_r=warm_r)
         torch.cuda.synchronize()
         assert (err_v[0].item(), err_r[0].item()) == ref_err
         assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
