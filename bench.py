@@ -99,9 +99,13 @@ def main():
     uniforms = torch.from_numpy(
         np.random.RandomState(1000 + rank).random_sample((total_steps, steps_per_rollout * n))).to(dev)
 
+    # N > 1: the policy network's gradients cross the links beside the value chain's backward pass
+    averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."))
+    engine.on_policy_grads = averager.start_early
+
     def one_step(i):
         res = engine.step(feats_d, prefix_d, steps_per_rollout, uniforms=uniforms[i])
-        ddp.average_gradients(flat.flat_grad)
+        averager.finish()
         opt.step()
         return res.check()  # reads the status word back: one host sync per step, as .item() in the reference loop
 

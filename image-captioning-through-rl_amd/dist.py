@@ -1,9 +1,12 @@
-"""Data-parallel exchange for the A2C step: one process per GPU, one collective per step.
+"""Data-parallel exchange for the A2C step: one process per GPU, the flat gradient buffer averaged
+once per step.
 
 Each rank runs the whole rollout / loss / backward on its own rows (the value and reward
 recurrences run over the rank's local rows only), then the flat float32 gradient buffer of
-policy + value network is summed across ranks and divided by the world size - a single
-all-reduce (RCCL over xGMI with backend "nccl"; gloo on CPU for tests).  Every rank then
+policy + value network is summed across ranks and divided by the world size (RCCL over xGMI
+with backend "nccl"; gloo on CPU for tests): as one all-reduce (average_gradients), or as two
+(GradientAverager) so that the policy network's part, complete milliseconds before the value
+network's, crosses the links beside the value chain's backward pass.  Every rank then
 applies the identical Adam update.  This equals `world` independent reference minibatches
 with averaged gradients, not one reference minibatch of world*N rows, because the
 reference's value / reward recurrences chain the rows of a minibatch together
@@ -54,6 +57,52 @@ def average_gradients(flat_grad):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         flat_grad.div_(world_size())
     return flat_grad
+
+
+class GradientAverager:
+    """In-place mean over ranks of a flat gradient buffer in two pieces: [lo, hi) as soon as the
+    caller knows it is complete (start_early), the rest in finish().  Every rank must make the same
+    calls in the same order, once per step each."""
+
+    def __init__(self, flat_grad, early_span):
+        self.flat_grad = flat_grad
+        self.lo, self.hi = early_span
+        assert 0 <= self.lo < self.hi <= flat_grad.numel()
+        self._work, self._stream = None, None
+
+    def start_early(self, ready_event=None):
+        """Start averaging flat_grad[lo:hi].  ready_event (CUDA): the event after which that range is
+        complete; the collective waits for it on a stream of its own."""
+        if not _active() or self._work is not None:
+            return
+        piece = self.flat_grad[self.lo:self.hi]
+        if piece.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=piece.device)
+            if ready_event is not None:
+                self._stream.wait_event(ready_event)
+            else:
+                self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                self._work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            self._work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """Average what start_early did not cover (everything, if it was not called), wait for the
+        early piece, divide by the world size.  The buffer is ready on the current stream afterwards."""
+        if not _active():
+            return self.flat_grad
+        if self._work is None:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+        else:
+            for lo, hi in ((0, self.lo), (self.hi, self.flat_grad.numel())):
+                if hi > lo:
+                    dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM)
+            self._work.wait()   # CUDA: the current stream waits for the collective's stream
+            self._work = None
+        self.flat_grad.div_(world_size())
+        return self.flat_grad
 
 
 def broadcast_parameters(flat, src=0):

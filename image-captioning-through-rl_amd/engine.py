@@ -60,6 +60,30 @@ class A2CStepResult:
         return self
 
 
+def _runs_beside(main, cand, cycles=4000000):
+    """True if a kernel on `cand` overlaps one on `main` (the current stream): two spins of `cycles`
+    clock ticks (milliseconds, so that the cross-stream event costs do not matter), one per stream,
+    take about as long as one."""
+    def spin_pair(second):
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(main)
+        torch.cuda._sleep(cycles)
+        if second is None:
+            torch.cuda._sleep(cycles)
+        else:
+            with torch.cuda.stream(second):
+                second.wait_event(t0)
+                torch.cuda._sleep(cycles)
+                done = torch.cuda.Event()
+                done.record(second)
+            main.wait_event(done)
+        t1.record(main)
+        t1.synchronize()
+        return t0.elapsed_time(t1)
+    serial = spin_pair(None)
+    return spin_pair(cand) < 0.75 * serial
+
+
 class _WarmupLadder:
     """Where one chain (value forward, reward forward, value backward) starts in the warm-up ladder.
 
@@ -137,6 +161,11 @@ class A2CEngine:
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
+        # on_policy_grads(event): called once per step as soon as the forward pass has been accepted, with
+        # the event after which the policy network's gradients are complete; a data-parallel caller starts
+        # their all-reduce there, beside the value chain's BPTT
+        self.on_policy_grads = None
+        self._ev_policy = None
         # every chain starts at the first rung of at least first_warmup steps (freshly initialised networks
         # pass there); shorter rungs are reached only by probing down
         start = next((i for i, w in enumerate(self.warmups) if w >= first_warmup), len(self.warmups) - 1)
@@ -183,7 +212,8 @@ class A2CEngine:
         ws = dict(tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev), tv=tv,
                   scalars=torch.zeros(8, dtype=torch.float32, device=dev),
                   status=torch.zeros(4, dtype=torch.int32, device=dev),
-                  seam=torch.zeros(6, dtype=torch.float32, device=dev))
+                  seam=torch.zeros(6, dtype=torch.float32, device=dev),
+                  seam_host=torch.zeros(4, dtype=torch.float32).pin_memory())
         widths = [H]
         if self.P is not None:
             v, e = self.vocab, self.E
@@ -264,8 +294,19 @@ class A2CEngine:
             self.trace.append((label, ev))
 
     def _side_stream(self):
+        """A second stream that really runs beside the current one.  HIP multiplexes its streams onto a
+        few hardware queues (4 per process by default), and two streams that share a queue run one
+        after the other; which streams collide depends on what else the process has created (an RCCL
+        communicator brings several), so candidates are tried until one overlaps."""
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream()
+            for attempt in range(8):
+                cand = torch.cuda.Stream(device=self.device)
+                if self._side is None:
+                    self._side = cand
+                if _runs_beside(main, cand):
+                    self._side = cand
+                    break
         return self._side
 
     def _rollout(self, ws, features, n, p0, s, uniforms, mode):
@@ -428,46 +469,63 @@ class A2CEngine:
         last = len(plans) - 1
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
-        redo_forward = True
+        # ---- chains forward + loss + backward, enqueued in one go; the forward seam errors come back
+        # through pinned memory as soon as the chains are done, so the host knows whether the attempt
+        # stands while the device is still busy with the backward pass.  A rejected forward seam redoes
+        # everything after the rollout; a rejected backward seam (below) only the value chain's BPTT.
         while True:
-            pv, pr, pb = plans[fv], plans[fr], plans[bi]
-            if redo_forward:
-                self._chains_loss_backward(ws, features, n, p0, s, mode, backward, main, side, pv, pr, pb)
-            else:  # only the value chain's BPTT was rejected: everything before it stands
-                self._value_chain_backward(ws, n, p0, s, main, side, pb, None)
-                self._mark("backward_done")
-            seg_v, seg_r, seg_b = pv[0] == "segmented", pr[0] == "segmented", with_bwd and pb[0] == "segmented"
-            if not (seg_v or seg_r or seg_b):
+            pv, pr = plans[fv], plans[fr]
+            if pv[0] == "exact":   # a value chain that no warm-up reproduced forward is not tried segmented backward
+                bi = last
+            pb = plans[bi]
+            ev_seam = self._chains_forward_loss(ws, features, n, p0, s, backward, main, side, pv, pr)
+            if with_bwd:
+                self._backward(ws, features, n, p0, s, main, side, pb)
+            self._mark("backward_done")
+            seg_v, seg_r = pv[0] == "segmented", pr[0] == "segmented"
+            if not (seg_v or seg_r):
                 break
-            seam = ws["seam"].tolist()  # host sync; the caller synchronises per step anyway
-            self.last_seam = seam
+            ev_seam.synchronize()
+            seam = ws["seam_host"].tolist()
             checks_v = [(seam[0], self.SEAM_TOL_FWD)] if seg_v else []
             checks_r = [(seam[2], self.SEAM_TOL_FWD)] if seg_r else []
-            checks_b = [(seam[4] / seam[5] if seam[5] > 0 else 0.0, self.SEAM_TOL_BWD)] if seg_b else []
-            ok_v, ok_r, ok_b = (all(e <= t for e, t in c) for c in (checks_v, checks_r, checks_b))
-            if ok_v and ok_r and ok_b:
+            ok_v, ok_r = (all(e <= t for e, t in c) for c in (checks_v, checks_r))
+            if ok_v and ok_r:
                 self._ladder_fv.accepted(fv, checks_v, last)
                 self._ladder_fr.accepted(fr, checks_r, last)
-                self._ladder_bwd.accepted(bi, checks_b, last)
                 break
             self.fallbacks += 1
-            redo_forward = not (ok_v and ok_r)
             if not ok_v:
                 fv = self._next_plan(plans, fv, checks_v)
                 self._ladder_fv.rejected(fv)
             if not ok_r:
                 fr = self._next_plan(plans, fr, checks_r)
                 self._ladder_fr.rejected(fr)
-            if not ok_b:
-                bi = self._next_plan(plans, bi, checks_b)
-                self._ladder_bwd.rejected(bi)
+        self.last_seam = ws["seam_host"].tolist()[:4] + [0.0, 0.0]
+        if with_bwd and self.on_policy_grads is not None:
+            # the forward pass stands, so the policy gradients being computed now are final
+            self.on_policy_grads(self._ev_policy)
+        while with_bwd and pb[0] == "segmented":
+            seam_b = ws["seam"][4:6].tolist()  # host sync; the caller synchronises per step anyway
+            self.last_seam[4:6] = seam_b
+            checks_b = [(seam_b[0] / seam_b[1] if seam_b[1] > 0 else 0.0, self.SEAM_TOL_BWD)]
+            if all(e <= t for e, t in checks_b):
+                self._ladder_bwd.accepted(bi, checks_b, last)
+                break
+            self.fallbacks += 1
+            bi = self._next_plan(plans, bi, checks_b)
+            self._ladder_bwd.rejected(bi)
+            pb = plans[bi]
+            self._value_chain_backward(ws, n, p0, s, main, side, pb, None)
+            self._mark("backward_done")
         return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                              ws["rewards"].view(s, n).t().contiguous(), ws["scalars"],
                              ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pv, pb), pr)
 
-    def _chains_loss_backward(self, ws, features, n, p0, s, mode, backward, main, side, plan, plan_r, plan_bwd):
-        """plan / plan_r: how the value / reward chain runs forward; plan_bwd: the value chain's BPTT."""
+    def _chains_forward_loss(self, ws, features, n, p0, s, backward, main, side, plan, plan_r):
+        """The two forward chains, the heads and the loss.  plan / plan_r: how the value / reward chain
+        runs.  Returns an event after which ws["seam_host"][:4] holds the forward seam errors."""
         P, V, R = self.P, self.V, self.R
         t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
         tok_flat = ws["tokT"].view(-1)
@@ -512,7 +570,9 @@ class A2CEngine:
                                    R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
                                    ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
                                    ws["seam"][0:2], ws["seam"][2:4], warmup_r=plan_r[2])
+        ev_seam = None
         if pair:
+            ev_seam = self._seam_to_host(ws, main)
             ev_pair = torch.cuda.Event()
             ev_pair.record(main)
             with torch.cuda.stream(side):
@@ -532,14 +592,21 @@ class A2CEngine:
         hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], s * n, n, ws["values"])
         self._mark("value_fwd_done")
         main.wait_event(ev_rew)
+        if ev_seam is None:
+            ev_seam = self._seam_to_host(ws, main)
 
         # ---- 3. loss (trainers.py:471-476)
         hip.a2c_loss(ws["values"], ws["rewards"], ws["logp"].view(-1), ws["scalars"],
                      ws["dvalue"] if backward else None, ws["dlogp"] if backward else None)
         self._mark("loss_done")
-        if backward and mode != hip.GREEDY:
-            self._backward(ws, features, n, p0, s, main, side, plan_bwd)
-        self._mark("backward_done")
+        return ev_seam
+
+    @staticmethod
+    def _seam_to_host(ws, stream):
+        ws["seam_host"].copy_(ws["seam"][:4], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
 
     def _reward_head(self, ws, features, n, s, stream, visual_done=False):
         """Semantic / visual embeddings and their cosine (models.py:235-240) on the current stream."""
@@ -615,6 +682,8 @@ class A2CEngine:
                 self._mark("side:policy_bwd_start")
                 self._policy_backward(ws, features, n, p0, s)
                 self._mark("side:policy_bwd_done")
+                self._ev_policy = torch.cuda.Event()
+                self._ev_policy.record(side)
             side.wait_event(ev_chain)
             ss = ws["scratch_side"]
             hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])

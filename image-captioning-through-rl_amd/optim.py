@@ -12,8 +12,16 @@ from . import hipabi as hip
 
 
 class FlatParams:
-    def __init__(self, params, flat, flat_grad, names):
-        self.params, self.flat, self.flat_grad, self.names = params, flat, flat_grad, names
+    def __init__(self, params, flat, flat_grad, names, offsets):
+        self.params, self.flat, self.flat_grad, self.names, self.offsets = params, flat, flat_grad, names, offsets
+
+    def span(self, prefix):
+        """[lo, hi) of the flat buffers covering the parameters whose names start with `prefix`
+        (they are neighbours: named_parameters() walks one submodule after the other)."""
+        idx = [i for i, name in enumerate(self.names) if name.startswith(prefix)]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), "no such parameters, or not contiguous: %r" % prefix
+        hi = self.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.offsets) else self.flat.numel()
+        return self.offsets[idx[0]], hi
 
 
 def flatten_module(module):
@@ -34,7 +42,7 @@ def flatten_module(module):
         view.copy_(p.data)
         p.data = view
         p.grad = flat_grad[off:off + p.numel()].view(p.shape)
-    return FlatParams([p for _, p in named], flat, flat_grad, [n for n, _ in named])
+    return FlatParams([p for _, p in named], flat, flat_grad, [n for n, _ in named], offsets)
 
 
 class FusedAdam(torch.optim.Optimizer):

@@ -188,10 +188,18 @@ def _a2c_minibatch(engine, optimizer, captions, features, p0, n_steps):
     # one double per (step, row), drawn from NumPy's global stream exactly as the reference's
     # N calls of np.random.choice per step do (trainers.py:447-449)
     uniforms = torch.from_numpy(np.random.random_sample(n_steps * n)).to(dev)
-    res = engine.step(feats, prefix, n_steps, uniforms=uniforms)
     flat = getattr(optimizer, "fp", None)
-    if flat is not None:
-        ddp.average_gradients(flat.flat_grad)
+    averager = None
+    if flat is not None and ddp.world_size() > 1:
+        # the policy network's gradients are complete well before the value network's: their all-reduce
+        # starts as soon as the engine says so and runs beside the value chain's backward pass
+        averager = getattr(engine, "_averager", None)
+        if averager is None or averager.flat_grad is not flat.flat_grad:
+            averager = engine._averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."))
+        engine.on_policy_grads = averager.start_early
+    res = engine.step(feats, prefix, n_steps, uniforms=uniforms)
+    if averager is not None:
+        averager.finish()
     optimizer.step()
     return res
 

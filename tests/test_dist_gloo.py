@@ -27,6 +27,19 @@ def _worker(rank, world, port, out_dir):
     for i, p in enumerate(net.parameters()):
         p.grad.fill_(float(rank + 1) * (i + 1))
     ddp.average_gradients(flat.flat_grad)
+    # the same average in two pieces (the second layer's gradients first), as the training loop does it
+    span = flat.span("1.")
+    pad = flat.flat_grad.numel()
+    two = torch.zeros(pad)
+    for i, (p, off) in enumerate(zip(net.parameters(), flat.offsets)):
+        two[off:off + p.numel()] = float(rank + 1) * (i + 1)
+    avg = ddp.GradientAverager(two, span)
+    avg.start_early()
+    avg.finish()
+    assert torch.equal(two, flat.flat_grad), "two-piece average differs from the single all-reduce"
+    whole = ddp.GradientAverager(two.clone(), span)
+    whole.finish()                                   # start_early never called: one all-reduce of everything
+    assert torch.allclose(whole.flat_grad, two)      # already equal on all ranks: the mean changes nothing
     lo, hi = ddp.shard_rows(1024)
     t = ddp.max_over_ranks(1.0 + rank, torch.device("cpu"))
     torch.save(dict(flat=flat.flat.clone(), grads=[p.grad.clone() for p in net.parameters()], shard=(lo, hi), t=t,
