@@ -143,6 +143,12 @@ def main():
         traffic = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
+    mfma_util = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_mfma.json")) as f:
+            mfma_util = {k: v["mfma_utilisation"] for k, v in json.load(f).items() if k != "_note"}
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
     achieved = gemm_flops / gemm_s / 1e12
     chains = {k: {"dependent_steps_per_minibatch": int(v[0] / args.steps), "us_per_step": 1e6 * v[1] / v[0],
                   "ms_per_minibatch": 1e3 * v[1] / args.steps}
@@ -195,7 +201,10 @@ def main():
                                    "chain input projections and weight gradients)",
                          "launches_per_step": gemm_launches // args.steps,
                          "gflop_per_step": gemm_flops / args.steps / 1e9,
-                         "ms_per_step_in_kernel": 1e3 * gemm_s / args.steps},
+                         "ms_per_step_in_kernel": 1e3 * gemm_s / args.steps,
+                         "mfma_utilisation_pmc": mfma_util,
+                         "mfma_utilisation_note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch cycles * 1024 SIMDs) per kernel, "
+                                                  "kernels run one at a time (profiles/pmc_mfma.json)"},
             "chains": chains,
             "mfma_work_of_whole_step": {
                 "gflop_executed_per_step": (gemm_flops / args.steps + seg_flops) / 1e9,
