@@ -1,0 +1,122 @@
+"""The A2C minibatch at the size the headline metric is quoted on (batch 512, vocabulary 10 000, T = 20,
+2048-d features), where the float64 oracle is too slow to be the checker.  Checked instead through
+(a) the exact chain kernels on the same inputs (GPU against GPU: the segment-parallel chains may not
+change anything beyond rounding), (b) run-to-run determinism, (c) the definition of the sampler
+(float64 inverse CDF of the stored probabilities, every one of the 9 728 draws) and of the stored
+log-probabilities, and (d) the reference-shaped float32 CPU port (pinned by the golden vectors at
+small sizes) for tokens and the three logged scalars.  Needs an MI355X: -m gpu."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import params_for, synthetic
+from oracle import cpu_port
+
+pytestmark = pytest.mark.gpu
+
+hip = importlib.import_module("image-captioning-through-rl_amd.hipabi")
+models = importlib.import_module("image-captioning-through-rl_amd.models")
+trainers = importlib.import_module("image-captioning-through-rl_amd.trainers")
+
+CFG = dict(n=512, vocab=10000, caplen=20, fdim=2048, seed=0, level=None)
+STEPS = CFG["caplen"] - 1
+
+
+def _modules():
+    w2i = synthetic.make_word_to_idx(CFG["vocab"])
+    nets = (models.PolicyNetwork(w2i, input_dim=CFG["fdim"]), models.ValueNetwork(w2i, feature_dim=CFG["fdim"]),
+            models.RewardNetwork(w2i, feature_dim=CFG["fdim"]))
+    for net, params in zip(nets, params_for(CFG)):
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        net.cuda()
+    nets[2].requires_grad_(False)
+    return models.AdvantageActorCriticNetwork(nets[1], nets[0]).cuda(), nets[2]
+
+
+@pytest.fixture(scope="module")
+def full_size():
+    feats, caps = synthetic.make_minibatch(CFG["n"], CFG["vocab"], CFG["caplen"], CFG["fdim"], 0)
+    u = synthetic.make_uniforms(0, STEPS * CFG["n"])
+    a2c, rew = _modules()
+    args = (torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :1]).cuda(), STEPS)
+    engine = trainers.build_engine(a2c, rew)
+    res = engine.step(*args, uniforms=torch.from_numpy(u).cuda()).check()
+    torch.cuda.synchronize()
+    out = dict(feats=feats, caps=caps, u=u, a2c=a2c, rew=rew, args=args, engine=engine, plan=res.chain_plan,
+               tokens=res.tokens.clone(), values=res.values.clone(), rewards=res.rewards.clone(),
+               log_probs=res.log_probs.clone(), scalars=res.scalars.clone(),
+               grads={k: p.grad.clone() for k, p in a2c.named_parameters()})
+    return out
+
+
+def test_segment_parallel_step_equals_the_exact_kernels_at_full_size(full_size):
+    fs = full_size
+    assert fs["plan"][0][0] == "segmented" and fs["plan"][1][0] == "segmented" and fs["engine"].fallbacks == 0
+    exact = trainers.build_engine(fs["a2c"], fs["rew"], chain_mode="exact")
+    res = exact.step(*fs["args"], uniforms=torch.from_numpy(fs["u"]).cuda()).check()
+    torch.cuda.synchronize()
+    assert res.chain_plan == (("exact",), ("exact",))
+    assert torch.equal(res.tokens, fs["tokens"])
+    np.testing.assert_allclose(fs["values"].cpu().numpy(), res.values.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(fs["rewards"].cpu().numpy(), res.rewards.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(fs["scalars"].cpu().numpy()[:5], res.scalars.cpu().numpy()[:5], rtol=1e-5, atol=1e-7)
+    for k, p in fs["a2c"].named_parameters():
+        scale = p.grad.pow(2).mean().sqrt().item() + 1e-12
+        assert (fs["grads"][k] - p.grad).abs().max().item() <= 1e-3 * scale + 1e-9, k
+
+
+def test_full_size_step_is_deterministic(full_size):
+    fs = full_size
+    again = trainers.build_engine(fs["a2c"], fs["rew"])
+    res = again.step(*fs["args"], uniforms=torch.from_numpy(fs["u"]).cuda()).check()
+    torch.cuda.synchronize()
+    assert res.chain_plan == fs["plan"]
+    assert torch.equal(res.tokens, fs["tokens"]) and torch.equal(res.values, fs["values"])
+    assert torch.equal(res.rewards, fs["rewards"]) and torch.equal(res.log_probs, fs["log_probs"])
+
+
+def test_every_draw_is_the_float64_inverse_cdf_of_its_stored_probabilities(full_size):
+    """numpy.random.choice(V, p=p) given its uniform u: cumsum in float64, divide by the last entry,
+    searchsorted(side="right") (trainers.py:447-449).  All 19 x 512 draws of the rollout."""
+    fs = full_size
+    n, v = CFG["n"], CFG["vocab"]
+    # the fixture's engine was the first to use these shapes: its workspace still holds the rollout
+    ws = fs["engine"]._ws[(n, 1, STEPS)]
+    tokens = fs["tokens"].cpu().numpy()
+    logp = fs["log_probs"].cpu().numpy()
+    u = fs["u"].reshape(STEPS, n)
+    fragile = 0
+    for k in range(STEPS):
+        probs = ws["probs"][k].cpu().numpy()
+        assert np.all(probs >= 0) and np.allclose(probs.sum(axis=1, dtype=np.float64), 1.0, atol=1e-5)
+        cdf = np.cumsum(probs.astype(np.float64), axis=1)
+        cdf /= cdf[:, -1:]
+        want = np.array([np.searchsorted(cdf[i], u[k, i], side="right") for i in range(n)])
+        got = tokens[:, 1 + k]
+        edge = np.abs(cdf - u[k][:, None]).min(axis=1)
+        differs = want != got
+        assert not np.any(differs & (edge > 1e-9)), "a draw differs away from a CDF edge"
+        fragile += int(differs.sum())
+        np.testing.assert_allclose(logp[:, k], np.log(probs[np.arange(n), got]), rtol=0, atol=2e-6)
+    assert fragile <= 2
+
+
+def test_full_size_step_against_the_reference_shaped_cpu_port(full_size):
+    """One minibatch of the float32 CPU port (full-prefix policy recompute, nn.LSTM / nn.GRU batch-1
+    chains, host inverse-CDF sampling, autograd) on the same inputs and uniforms: the same tokens, and the
+    three scalars the reference logs to rtol 5e-4 (float32 sums over 10^5-step chains in different orders)."""
+    fs = full_size
+    pol, val, rew = params_for(CFG)
+    nets = cpu_port.PortNets(pol, val, rew, CFG["vocab"], CFG["fdim"])
+    out = cpu_port.a2c_minibatch(nets, cpu_port.make_optimizer(nets), fs["feats"], fs["caps"], uniforms=fs["u"])
+    same = out["tokens"] == fs["tokens"].cpu().numpy()
+    assert same.mean() > 0.9995, "sampled tokens differ from the CPU port's"
+    # a draw within float32 rounding of a CDF edge may fall either way (the two softmaxes differ in the last
+    # bit); the rows it touches then see other tokens, so the scalars are only compared loosely
+    rtol = 5e-4 if same.all() else 2e-2
+    print("tokens that differ from the CPU port: %d of %d" % ((~same).sum(), same.size))
+    sc = fs["scalars"].cpu().numpy()
+    for got, want in ((sc[0], out["loss"]), (sc[3], out["mean_reward"]), (sc[4], out["mean_advantage"])):
+        assert abs(got - want) <= rtol * abs(want) + 1e-5, (got, want, rtol)
