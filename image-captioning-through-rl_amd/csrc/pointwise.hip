@@ -88,6 +88,32 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(float* __restrict__ 
     }
 }
 
+// batched GRU cell (PyTorch gate order r, z, n): gx = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both [n, 3H]
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ gh,
+                                                           const float* __restrict__ h_prev,
+                                                           float* __restrict__ h_out, int n) {
+    const int64_t total = (int64_t)n * (H / 4);
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int row = (int)(e / (H / 4)), j4 = (int)(e % (H / 4));
+        const float4* x = reinterpret_cast<const float4*>(gx + (int64_t)row * 3 * H);
+        const float4* g = reinterpret_cast<const float4*>(gh + (int64_t)row * 3 * H);
+        const float4 xr = x[j4], xz = x[H / 4 + j4], xn = x[2 * (H / 4) + j4];
+        const float4 hr = g[j4], hz = g[H / 4 + j4], hn = g[2 * (H / 4) + j4];
+        const float4 hp = reinterpret_cast<const float4*>(h_prev)[e];
+        float4 h;
+#define ICRL_GRU(k)                                             \
+    {                                                           \
+        const float r_ = sigmoidf_(xr.k + hr.k);                \
+        const float z_ = sigmoidf_(xz.k + hz.k);                \
+        const float n_ = tanhf_(xn.k + r_ * hn.k);              \
+        h.k = n_ + z_ * (hp.k - n_);                            \
+    }
+        ICRL_GRU(x) ICRL_GRU(y) ICRL_GRU(z) ICRL_GRU(w)
+#undef ICRL_GRU
+        reinterpret_cast<float4*>(h_out)[e] = h;
+    }
+}
+
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates,
                                                             const float* __restrict__ c_prev,
                                                             const float* __restrict__ c,
@@ -435,6 +461,15 @@ extern "C" int icrl_lstm_cell_fwd(float* gates, const float* c_prev, float* c, f
     ICRL_REQUIRE(gates && c_prev && c && h && N > 0, "icrl_lstm_cell_fwd: null pointer or N <= 0");
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((int64_t)N * H / 4, 256)), dim3(256), 0,
                        as_stream(stream), gates, c_prev, c, h, N);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_gru_cell_fwd(const float* gx, const float* gh, const float* h_prev, float* h, int N,
+                                 icrl_stream_t stream) {
+    ICRL_REQUIRE(gx && gh && h_prev && h && N > 0, "icrl_gru_cell_fwd: null pointer or N <= 0");
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(grid_for((int64_t)N * H / 4, 256)), dim3(256), 0,
+                       as_stream(stream), gx, gh, h_prev, h, N);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

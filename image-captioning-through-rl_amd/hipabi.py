@@ -40,6 +40,7 @@ SIGNATURES = {
     "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "icrl_gru_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_policy_lstm_step": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                       c_vp]),
@@ -186,6 +187,11 @@ def colsum(x, out, accumulate=False, rows=None):
     _check(load().icrl_colsum(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(out), int(accumulate), _stream()),
            "icrl_colsum")
     return out
+
+
+def gru_cell_fwd(gx, gh, h_prev, h):
+    _check(load().icrl_gru_cell_fwd(_ptr(_f32c(gx)), _ptr(_f32c(gh)), _ptr(_f32c(h_prev)), _ptr(_f32c(h)),
+                                    gx.shape[0], _stream()), "icrl_gru_cell_fwd")
 
 
 def lstm_cell_fwd(gates, c_prev, c, h):

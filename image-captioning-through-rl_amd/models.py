@@ -107,12 +107,16 @@ class ValueNetworkRNN(nn.Module):
     ``hidden_cell`` until ``init_hidden()`` (models.py:87-135)."""
 
     def __init__(self, word_to_idx, input_dim=512, wordvec_dim=512, hidden_dim=512,
-                 pretrained_embeddings=None, bidirectional=False):
+                 pretrained_embeddings=None, bidirectional=False, per_sample=False):
         super().__init__()
         _no_bidirectional(bidirectional)
         assert hidden_dim == H
         self.bidirectional = bidirectional
         self.hidden_dim = hidden_dim
+        # per_sample: every row of a batch keeps its own (h, c) across calls until init_hidden() - what the
+        # reference computes when it is called with one image at a time.  Never a default.
+        self.per_sample = per_sample
+        self._row_state = None
         self.word_to_idx = word_to_idx
         self.idx_to_word = {i: w for w, i in word_to_idx.items()}
         self.caption_embedding, wordvec_dim = _embedding(len(word_to_idx), wordvec_dim, pretrained_embeddings)
@@ -122,6 +126,7 @@ class ValueNetworkRNN(nn.Module):
 
     def init_hidden(self):
         self.hidden_cell = (torch.zeros(1, 1, self.hidden_dim).to(device), torch.zeros(1, 1, self.hidden_dim).to(device))
+        self._row_state = None
 
     @torch.no_grad()
     def forward_columns(self, tok_t):
@@ -132,6 +137,20 @@ class ValueNetworkRNN(nn.Module):
         xproj = torch.empty(p * n, 4 * H, device=dev)
         hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, xproj, a_rows=tok_t.reshape(-1),
                  bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
+        if self.per_sample:
+            # N chains side by side: one [N,512] x W_hh^T product and one cell launch per column
+            if self._row_state is None or self._row_state[0].shape[0] != n:
+                self._row_state = (torch.zeros(n, H, device=dev), torch.zeros(n, H, device=dev))
+            h, c = self._row_state
+            for t in range(p):
+                gates = xproj[t * n:(t + 1) * n]
+                hip.gemm(h, self.lstm.weight_hh_l0, gates, accumulate=True)
+                h_next, c_next = torch.empty_like(h), torch.empty_like(c)
+                hip.lstm_cell_fwd(gates, c, c_next, h_next)
+                h, c = h_next, c_next
+            self._row_state = (h, c)
+            self.hidden_cell = (h.view(1, n, H), c.view(1, n, H))
+            return h
         state = torch.cat((self.hidden_cell[0].reshape(-1), self.hidden_cell[1].reshape(-1))).to(dev).contiguous()
         state_out = torch.empty_like(state)
         h_emit = torch.empty(1, n, H, device=dev)
@@ -153,11 +172,13 @@ class ValueNetwork(nn.Module):
     """Critic: last column's chain outputs concatenated with the image features, two
     linear layers with no activation between them (models.py:138-180)."""
 
-    def __init__(self, word_to_idx, pretrained_embeddings=None, bidirectional=False, feature_dim=512):
+    def __init__(self, word_to_idx, pretrained_embeddings=None, bidirectional=False, feature_dim=512,
+                 per_sample=False):
         super().__init__()
         _no_bidirectional(bidirectional)
         self.bidirectional = bidirectional
-        self.valrnn = ValueNetworkRNN(word_to_idx, pretrained_embeddings=pretrained_embeddings, bidirectional=False)
+        self.valrnn = ValueNetworkRNN(word_to_idx, pretrained_embeddings=pretrained_embeddings, bidirectional=False,
+                                      per_sample=per_sample)
         self.linear1 = nn.Linear(feature_dim + 512, 512)
         self.linear2 = nn.Linear(512, 1)
 
@@ -182,12 +203,14 @@ class RewardNetworkRNN(nn.Module):
     """Embedding + GRU, batch-as-sequence like ValueNetworkRNN (models.py:183-228)."""
 
     def __init__(self, word_to_idx, input_dim=512, wordvec_dim=512, hidden_dim=512,
-                 pretrained_embeddings=None, bidirectional=False):
+                 pretrained_embeddings=None, bidirectional=False, per_sample=False):
         super().__init__()
         _no_bidirectional(bidirectional)
         assert hidden_dim == H
         self.bidirectional = bidirectional
         self.hidden_dim = hidden_dim
+        self.per_sample = per_sample   # one recurrent state per row, as in ValueNetworkRNN
+        self._row_state = None
         self.word_to_idx = word_to_idx
         self.idx_to_word = {i: w for w, i in word_to_idx.items()}
         self.caption_embedding, wordvec_dim = _embedding(len(word_to_idx), wordvec_dim, pretrained_embeddings)
@@ -197,6 +220,7 @@ class RewardNetworkRNN(nn.Module):
 
     def init_hidden(self):
         self.hidden_cell = torch.zeros(1, 1, self.hidden_dim).to(device)
+        self._row_state = None
 
     @torch.no_grad()
     def forward_columns(self, tok_t):
@@ -205,6 +229,19 @@ class RewardNetworkRNN(nn.Module):
         xproj = torch.empty(p * n, 3 * H, device=dev)
         hip.gemm(self.caption_embedding.weight, self.gru.weight_ih_l0, xproj, a_rows=tok_t.reshape(-1),
                  bias=self.gru.bias_ih_l0)
+        if self.per_sample:
+            if self._row_state is None or self._row_state.shape[0] != n:
+                self._row_state = torch.zeros(n, H, device=dev)
+            h = self._row_state
+            gh = torch.empty(n, 3 * H, device=dev)
+            for t in range(p):
+                hip.gemm(h, self.gru.weight_hh_l0, gh, bias=self.gru.bias_hh_l0)
+                h_next = torch.empty_like(h)
+                hip.gru_cell_fwd(xproj[t * n:(t + 1) * n], gh, h, h_next)
+                h = h_next
+            self._row_state = h
+            self.hidden_cell = h.view(1, n, H)
+            return h
         state = self.hidden_cell.reshape(-1).to(dev).contiguous()
         state_out = torch.empty_like(state)
         h_emit = torch.empty(1, n, H, device=dev)
@@ -225,11 +262,13 @@ class RewardNetwork(nn.Module):
     """Projects caption (GRU chain) and image features into one embedding space
     (models.py:231-262)."""
 
-    def __init__(self, word_to_idx, pretrained_embeddings=None, bidirectional=False, feature_dim=512):
+    def __init__(self, word_to_idx, pretrained_embeddings=None, bidirectional=False, feature_dim=512,
+                 per_sample=False):
         super().__init__()
         _no_bidirectional(bidirectional)
         self.bidirectional = bidirectional
-        self.rewrnn = RewardNetworkRNN(word_to_idx, pretrained_embeddings=pretrained_embeddings, bidirectional=False)
+        self.rewrnn = RewardNetworkRNN(word_to_idx, pretrained_embeddings=pretrained_embeddings, bidirectional=False,
+                                       per_sample=per_sample)
         self.visual_embed = nn.Linear(feature_dim, 512)
         self.semantic_embed = nn.Linear(512, 512)
 

@@ -167,7 +167,10 @@ def _grads_of(module):
 
 
 def build_engine(a2c_network, reward_network, **engine_options):
-    """Bind an A2CEngine to the live parameter / gradient storage of the modules."""
+    """Bind an A2CEngine to the live parameter / gradient storage of the modules.  Modules built with
+    per_sample=True get the engine's per-image recurrent state too, unless chain_semantics is given."""
+    if getattr(a2c_network.value_network.valrnn, "per_sample", False):
+        engine_options.setdefault("chain_semantics", "per_sample")
     return A2CEngine(_params_of(a2c_network.policy_network), _params_of(a2c_network.value_network),
                      _params_of(reward_network), _grads_of(a2c_network.policy_network),
                      _grads_of(a2c_network.value_network), **engine_options)
@@ -400,6 +403,7 @@ def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirecti
     results_save_path = save_paths["results_path"]
     w2i, emb = train_data["word_to_idx"], train_data["embeddings"]
     fdim = int(np.asarray(train_data["train_features"]).shape[1])
+    per_sample = chain_semantics == "per_sample"
 
     def train_reward():
         return train_reward_network(train_data, network_paths, plot_dir, bidirectional, batch_size=batch_size)
@@ -416,14 +420,19 @@ def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirecti
         print_green('[Training] All networks trained')
     else:
         reward_network = _load_or_train(
-            lambda: RewardNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device),
+            lambda: RewardNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim,
+                                  per_sample=per_sample).to(device),
             network_paths["reward_network"], "reward network", train_reward)
         policy_network = _load_or_train(
             lambda: PolicyNetwork(w2i, input_dim=fdim, pretrained_embeddings=emb, bidirectional=bidirectional).to(device),
             network_paths["policy_network"], "policy network", train_policy)
         value_network = _load_or_train(
-            lambda: ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device),
+            lambda: ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim,
+                                 per_sample=per_sample).to(device),
             network_paths["value_network"], "value network", train_value)
+    # the pre-training loops always run the reference's batch-1 recurrences; what the trained modules
+    # compute from here on (A2C steps, decoding) follows chain_semantics
+    value_network.valrnn.per_sample = reward_network.rewrnn.per_sample = per_sample
     reward_network.requires_grad_(False)
     reward_network.train(False)
     a2c_network = AdvantageActorCriticNetwork(value_network, policy_network).to(device)

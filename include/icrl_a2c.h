@@ -87,6 +87,11 @@ int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int
  *      dgates[N,4H] (w.r.t. the pre-activations) and dc_prev. */
 int icrl_lstm_cell_fwd(float* gates, const float* c_prev, float* c, float* h, int N,
                        icrl_stream_t stream);
+/* Pointwise part of nn.GRU for N rows at once (models.py:226 run with one recurrent state per row):
+ * gx = x W_ih^T + b_ih and gh = h_prev W_hh^T + b_hh, both [N, 3*512] in gate order r, z, n;
+ * h = (1 - z) n + z h_prev with r = sigmoid(xr + hr), z = sigmoid(xz + hz), n = tanh(xn + r hn). */
+int icrl_gru_cell_fwd(const float* gx, const float* gh, const float* h_prev, float* h, int N,
+                      icrl_stream_t stream);
 int icrl_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float* c,
                        const float* dh, const float* dc, float* dgates, float* dc_prev, int N,
                        icrl_stream_t stream);

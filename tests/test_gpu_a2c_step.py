@@ -344,6 +344,36 @@ def test_per_sample_chains_match_reference_at_batch_size_one(name, persistent):
         check_summary(g, "grad", k, p.grad.cpu().numpy(), 2e-3, 1e-7)
 
 
+@pytest.mark.parametrize("name", GOLDEN_PER_SAMPLE)
+def test_per_sample_module_forwards_match_reference_at_batch_size_one(name):
+    """ValueNetwork / RewardNetwork built with per_sample=True, called on a batch with growing prefixes
+    (state kept across the calls, as in the reference's rollout): per image what the reference's classes
+    gave when its loop was fed one image per minibatch.  init_hidden() starts every row from zeros again."""
+    g = load_lookahead(name)
+    cfg = g["cfg"]
+    n, steps = cfg["n"], cfg["caplen"] - 1
+    w2i = synthetic.make_word_to_idx(cfg["vocab"])
+    val = models.ValueNetwork(w2i, feature_dim=cfg["fdim"], per_sample=True)
+    rew = models.RewardNetwork(w2i, feature_dim=cfg["fdim"], per_sample=True)
+    _, vp, rp = params_for(cfg)
+    for net, params in ((val, vp), (rew, rp)):
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        net.cuda()
+    feats = torch.from_numpy(g["features"]).cuda()
+    toks = torch.from_numpy(g["tokens"]).cuda()
+    for attempt in range(2):
+        val.valrnn.init_hidden()
+        rew.rewrnn.init_hidden()
+        for k in range(steps):
+            v = val(feats, toks[:, :1 + k])
+            r = trainers.GetRewards(feats, toks[:, :2 + k], rew)
+            assert tuple(v.shape) == (n, 1) and tuple(r.shape) == (n, 1)
+            np.testing.assert_allclose(v[:, 0].cpu().numpy(), g["values"][:, k], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(r[:, 0].cpu().numpy(), g["rewards"][:, k], rtol=RTOL, atol=ATOL)
+    a2c = models.AdvantageActorCriticNetwork(val, models.PolicyNetwork(w2i, input_dim=cfg["fdim"]).cuda())
+    assert trainers.build_engine(a2c, rew).per_sample   # the engine follows the modules
+
+
 @pytest.mark.parametrize("n,vocab,caplen,fdim", [(70, 300, 9, 2048), (1, 50, 5, 512)])
 def test_per_sample_step_matches_float64_oracle_and_both_launch_modes_agree(n, vocab, caplen, fdim):
     """Per-row chains on a batch that is not a multiple of the 32-row tiles (and on a single row, where
