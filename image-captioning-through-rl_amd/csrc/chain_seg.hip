@@ -49,6 +49,26 @@ using namespace icrl::seg;
     GRU_CELL1(x, xr, xz, xn, hr, hz, hn, hp, h) GRU_CELL1(y, xr, xz, xn, hr, hz, hn, hp, h) \
     GRU_CELL1(z, xr, xz, xn, hr, hz, hn, hp, h) GRU_CELL1(w, xr, xz, xn, hr, hz, hn, hp, h)
 
+#define GRU_GATES1(k, xr, xz, xn, hr, hz, hn, r4, z4, n4)                     \
+    r4.k = sg(xr.k + hr.k); z4.k = sg(xz.k + hz.k); n4.k = th(__fmaf_rn(r4.k, hn.k, xn.k));
+#define GRU_GATES4(xr, xz, xn, hr, hz, hn, r4, z4, n4) \
+    GRU_GATES1(x, xr, xz, xn, hr, hz, hn, r4, z4, n4) GRU_GATES1(y, xr, xz, xn, hr, hz, hn, r4, z4, n4) \
+    GRU_GATES1(z, xr, xz, xn, hr, hz, hn, r4, z4, n4) GRU_GATES1(w, xr, xz, xn, hr, hz, hn, r4, z4, n4)
+// GRU cell backward for one component: DH = total gradient of the position's output h
+#define GRU_BWD1(k, DH, GR, GZ, GN, GHN, HP, DR, DZ, DN, DHN, CY)            \
+    {                                                                        \
+        DN.k = DH.k * (1.f - GZ.k) * __fmaf_rn(-GN.k, GN.k, 1.f);            \
+        DZ.k = DH.k * (HP.k - GN.k) * GZ.k * (1.f - GZ.k);                   \
+        DR.k = DN.k * GHN.k * GR.k * (1.f - GR.k);                           \
+        DHN.k = DN.k * GR.k;                                                 \
+        CY.k = DH.k * GZ.k;                                                  \
+    }
+#define GRU_BWD4(DH, GR, GZ, GN, GHN, HP, DR, DZ, DN, DHN, CY)                \
+    GRU_BWD1(x, DH, GR, GZ, GN, GHN, HP, DR, DZ, DN, DHN, CY)                 \
+    GRU_BWD1(y, DH, GR, GZ, GN, GHN, HP, DR, DZ, DN, DHN, CY)                 \
+    GRU_BWD1(z, DH, GR, GZ, GN, GHN, HP, DR, DZ, DN, DHN, CY)                 \
+    GRU_BWD1(w, DH, GR, GZ, GN, GHN, HP, DR, DZ, DN, DHN, CY)
+
 #define LSTM_BWD1(k, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)  \
     {                                                                           \
         const float tc = th(cc.k);                                              \
@@ -280,6 +300,12 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
             const float4 hz = add4(sum_partials(pr + 32 * PLD), ld4(b_hh + H + u));
             const float4 hn = add4(sum_partials(pr + 64 * PLD), ld4(b_hh + 2 * H + u));
             GRU_CELL4(xr_, xz, xn, hr_, hz, hn, pprev[ii], h)
+            if (qs >= 0 && saved) {   // {r, z, n, hn, h}: the same expressions as in the cell, so the same bits
+                float4 r4, z4, n4;
+                GRU_GATES4(xr_, xz, xn, hr_, hz, hn, r4, z4, n4)
+                float* sp = saved + pos * (5 * H) + u;
+                st4(sp, r4); st4(sp + H, z4); st4(sp + 2 * H, n4); st4(sp + 3 * H, hn); st4(sp + 4 * H, h);
+            }
         }
         st4(h_nxt + (int64_t)j * H + u, h);
         if (qs >= 0 && t == g.p0 + s - 1) st4(h_emit + ((int64_t)s * g.n + i) * H + u, h);
@@ -442,6 +468,133 @@ __global__ __launch_bounds__(256) void seg_bwd_step(const float* __restrict__ dg
     if (qs < g.Ls) {
         float* dp = dgv + pos * (4 * H) + u;
         st4(dp, d_i); st4(dp + H, d_f); st4(dp + 2 * H, d_g); st4(dp + 3 * H, d_o);
+    }
+}
+
+// ------------------------------------------------------------------ GRU backward step
+// The same scheme for the reward GRU (the BPTT the reward pre-training loop needs, trainers.py:288-300).
+// State entering a position (walking down): P = W_hh^T dgates_h(pos+1), and the carry dh(pos+1) * z(pos+1);
+// dh(pos) = P + carry + injected gradient.  The four waves split the 1536 rows of dgates_h (384 each).
+// Outputs per position: dgates_x = {dr, dz, dn} (gradient of x W_ih^T + b_ih) and dgates_h = {dr, dz, r dn}
+// (gradient of h W_hh^T + b_hh).  saved = {r, z, n, hn, h} per position.
+__global__ __launch_bounds__(256) void seg_gru_bwd_step(const float* __restrict__ dg_prev, const float* __restrict__ w_hh,
+                                                        const float* __restrict__ saved, const float* __restrict__ d_emit,
+                                                        float* __restrict__ carry, float* __restrict__ dg_next,
+                                                        float* __restrict__ dgx, float* __restrict__ dgh,
+                                                        float* __restrict__ seam_a, float* __restrict__ dh_out, Geom g,
+                                                        int mp, int final) {
+    constexpr int A_T = 32 * LDT, B_T = BK * 32, STAGE = 4 * (A_T + B_T);
+    constexpr int KW = 3 * H / 4;              // gate rows per wave
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int row0 = blockIdx.y * 32, u0 = blockIdx.x * 32;
+
+    const int rr = tid >> 3, uq = 4 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    const int qs = g.Ls + g.W - 1 - mp;
+    const int64_t pos = seg_pos(g, j, qs);
+    const bool have_row = j < g.K;
+    const bool live = have_row && !final && pos < g.total && seg_pos(g, j, 0) < g.total;
+    float4 gr = zero4(), gz = zero4(), gn = zero4(), ghn = zero4(), hp = zero4(), de = zero4(), cin = zero4();
+    if (have_row && !final) cin = ld4(carry + (int64_t)j * H + u);
+    if (live) {
+        int s, t, i;
+        locate_fast(g, (int)pos, s, t, i);
+        const float* sp = saved + pos * (5 * H) + u;
+        gr = ld4(sp); gz = ld4(sp + H); gn = ld4(sp + 2 * H); ghn = ld4(sp + 3 * H);
+        if (pos >= g.stride) hp = ld4(saved + (pos - g.stride) * (5 * H) + 4 * H + u);
+        if (t == g.p0 + s - 1) de = ld4(d_emit + ((int64_t)s * g.n + i) * H + u);
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (mp > 0) {
+        const float* asrc[8];
+        int adst[8];
+        const float* bsrc[8];
+        int bdst[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + 256 * i;
+            const int ww = f >> 9, r = (f >> 4) & 31, kq = f & 15;
+            asrc[i] = dg_prev + (int64_t)min(row0 + r, g.K - 1) * (3 * H) + ww * KW + 4 * kq;
+            adst[i] = ww * (A_T + B_T) + r * LDT + 4 * kq;
+            const int kk = (f >> 3) & 63, uq2 = f & 7;
+            bsrc[i] = w_hh + (int64_t)(ww * KW + kk) * H + u0 + 4 * uq2;
+            bdst[i] = ww * (A_T + B_T) + A_T + kk * 32 + 4 * uq2;
+        }
+        float4 sa[8], sb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sa[i] = ld4(asrc[i]); sb[i] = ld4(bsrc[i]); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { st4(lds + adst[i], sa[i]); st4(lds + bdst[i], sb[i]); }
+        __syncthreads();
+        constexpr int NK = KW / BK;
+        for (int kt = 0; kt < NK; ++kt) {
+            const float* cur = lds + (kt & 1) * STAGE + w * (A_T + B_T);
+            if (kt + 1 < NK) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    sa[i] = ld4(asrc[i] + (kt + 1) * BK);
+                    sb[i] = ld4(bsrc[i] + (int64_t)(kt + 1) * BK * H);
+                }
+            }
+            const float* a_row = cur + l31 * LDT;
+            const float* b_t = cur + A_T;
+#pragma unroll
+            for (int grp = 0; grp < BK / 16; ++grp) {
+                const float4 a0 = ld4(a_row + 16 * grp + 8 * hh), a1 = ld4(a_row + 16 * grp + 8 * hh + 4);
+                const float* bk = b_t + (16 * grp + 8 * hh) * 32 + l31;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bk[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bk[32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bk[64], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bk[96], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bk[128], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bk[160], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bk[192], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bk[224], acc, 0, 0, 0);
+            }
+            if (kt + 1 < NK) {
+                float* nxt = lds + ((kt + 1) & 1) * STAGE;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { st4(nxt + adst[i], sa[i]); st4(nxt + bdst[i], sb[i]); }
+            }
+            __syncthreads();
+        }
+    }
+    float* P = lds;
+    acc_to_lds(acc, P + w * 32 * PLD, l31, hh);
+    __syncthreads();
+
+    if (!have_row) return;
+    const float* pr = P + rr * PLD + uq;
+    const float4 prod = add4(add4(ldp4(pr), ldp4(pr + 32 * PLD)), add4(ldp4(pr + 64 * PLD), ldp4(pr + 96 * PLD)));
+    if (final) {
+        st4(dh_out + (int64_t)j * H + u, prod);
+        return;
+    }
+    if (qs == g.Ls - 1) {  // state entering the segment's last own position
+        st4(seam_a + (int64_t)j * 2 * H + u, prod);
+        st4(seam_a + (int64_t)j * 2 * H + H + u, cin);
+    }
+    float* dgo = dg_next + (int64_t)j * (3 * H) + u;
+    if (!live) {
+        st4(dgo, zero4()); st4(dgo + H, zero4()); st4(dgo + 2 * H, zero4());
+        st4(carry + (int64_t)j * H + u, zero4());
+        return;
+    }
+    const float4 dh = add4(add4(prod, cin), de);
+    float4 dr, dz, dn, dhn, cy;
+    GRU_BWD4(dh, gr, gz, gn, ghn, hp, dr, dz, dn, dhn, cy)
+    st4(dgo, dr); st4(dgo + H, dz); st4(dgo + 2 * H, dhn);
+    st4(carry + (int64_t)j * H + u, cy);
+    if (qs < g.Ls) {
+        float* dx = dgx + pos * (3 * H) + u;
+        float* dg = dgh + pos * (3 * H) + u;
+        st4(dx, dr); st4(dx + H, dz); st4(dx + 2 * H, dn);
+        st4(dg, dr); st4(dg + H, dz); st4(dg + 2 * H, dhn);
     }
 }
 
@@ -968,7 +1121,7 @@ int fwd_steps_lstm(const Geom& g, const float* xproj, const float* w_hh, float* 
 }
 
 int fwd_steps_gru(const Geom& g, const float* xproj, const float* w_hh, const float* b_hh, float* h_emit,
-                   float* work, hipStream_t st) {
+                   float* saved, float* work, hipStream_t st) {
     const int64_t kh = (int64_t)g.K * H;
     float* hb[2] = {work, work + kh};
     ICRL_HIP(hipMemsetAsync(work, 0, sizeof(float) * 2 * kh, st));
@@ -976,7 +1129,7 @@ int fwd_steps_gru(const Geom& g, const float* xproj, const float* w_hh, const fl
     for (int m = 0; m < g.W + g.Ls; ++m) {
         const int cur = m & 1;
         hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
-                           (float*)nullptr, hb[cur ^ 1], (float*)nullptr, h_emit, work + 2 * kh, work + 3 * kh, g, m);
+                           (float*)nullptr, hb[cur ^ 1], saved, h_emit, work + 2 * kh, work + 3 * kh, g, m);
     }
     return ICRL_OK;
 }
@@ -1056,8 +1209,8 @@ extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, in
 }
 
 extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                      int n_calls, int segments, int warmup, float* h_emit, float* work,
-                                      float* seam_err, icrl_stream_t stream) {
+                                      int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                                      float* work, float* seam_err, icrl_stream_t stream) {
     Geom g;
     if (int rc = make_geom("icrl_gru_chain_fwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && b_hh && h_emit && work && seam_err, "icrl_gru_chain_fwd_seg: null pointer");
@@ -1066,7 +1219,8 @@ extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, con
     hipStream_t st = icrl::as_stream(stream);
     const int64_t kh = (int64_t)g.K * H;
     ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
-    if (int rc = fwd_steps_gru(g, xproj, w_hh, b_hh, h_emit, work, st)) return rc;
+    ICRL_REQUIRE(aligned16(saved), "icrl_gru_chain_fwd_seg: buffers must be 16-byte aligned");
+    if (int rc = fwd_steps_gru(g, xproj, w_hh, b_hh, h_emit, saved, work, st)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * H)), dim3(256), 0, st, work + 2 * kh, work + 3 * kh, g, H,
                        seam_err);
     ICRL_LAUNCH_CHECK();
@@ -1087,6 +1241,34 @@ extern "C" int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, co
     if (int rc = bwd_steps(g, w_hh, saved, d_emit, dgates, work, st)) return rc;
     hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, work + 9 * kh, work + 11 * kh,
                        work + 8 * kh, g, seam_err, seam_err + 1);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_gru_chain_bwd_seg(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                                      int n_calls, int segments, int warmup, float* dgates_x, float* dgates_h,
+                                      float* work, float* seam_err, icrl_stream_t stream) {
+    Geom g;
+    if (int rc = make_geom("icrl_gru_chain_bwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
+    ICRL_REQUIRE(w_hh && saved && d_emit && dgates_x && dgates_h && work && seam_err,
+                 "icrl_gru_chain_bwd_seg: null pointer");
+    ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates_x) &&
+                 aligned16(dgates_h) && aligned16(work), "icrl_gru_chain_bwd_seg: buffers must be 16-byte aligned");
+    hipStream_t st = icrl::as_stream(stream);
+    const int64_t kh = (int64_t)g.K * H;
+    float* dg[2] = {work, work + 4 * kh};  // [K, 3H] each
+    float* carry = work + 8 * kh;          // [K, H]
+    float* seam_a = work + 9 * kh;         // [K, 2H]
+    float* dh_fin = work + 11 * kh;        // [K, H]
+    ICRL_HIP(hipMemsetAsync(carry, 0, sizeof(float) * 3 * kh, st));
+    ICRL_HIP(hipMemsetAsync(seam_err, 0, 2 * sizeof(float), st));
+    const dim3 grid(H / 32, (g.K + 31) / 32);
+    const int steps = g.W + g.Ls;
+    for (int mp = 0; mp <= steps; ++mp)
+        hipLaunchKernelGGL(seg_gru_bwd_step, grid, dim3(256), 0, st, dg[(mp & 1) ^ 1], w_hh, saved, d_emit, carry,
+                           dg[mp & 1], dgates_x, dgates_h, seam_a, dh_fin, g, mp, mp == steps ? 1 : 0);
+    hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, seam_a, dh_fin, carry, g,
+                       seam_err, seam_err + 1);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -1184,7 +1366,7 @@ extern "C" int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_
         hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
     } else {
         if (int rc = fwd_steps_lstm(v.g, xproj_v, w_hh_v, h_emit_v, saved_v, work_v, st)) return rc;
-        if (int rc = fwd_steps_gru(r.g, xproj_r, w_hh_r, b_hh_r, h_emit_r, work_r, st)) return rc;
+        if (int rc = fwd_steps_gru(r.g, xproj_r, w_hh_r, b_hh_r, h_emit_r, nullptr, work_r, st)) return rc;
     }
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;

@@ -23,7 +23,7 @@ The two recurrences can be evaluated in two ways (``chain_mode``):
     own warm-up length; a rejected backward seam redoes only the value chain's BPTT.  With
     ``persistent`` (default) and at most 512 segments all steps of the two forward chains
     run in one launch, and all steps of the backward chain in another;
-  * "auto" (default): segmented for chains of at least 8192 positions, else exact.
+  * "auto" (default): segmented for chains of at least 4096 positions, else exact.
 
 ``chain_semantics="per_sample"`` is an explicit change of what is computed, never a default: every
 image owns its recurrent state (the reference's own classes called with one image at a time,
@@ -172,7 +172,8 @@ class A2CEngine:
         # every chain starts at the first rung of at least first_warmup steps (freshly initialised networks
         # pass there); shorter rungs are reached only by probing down
         start = next((i for i, w in enumerate(self.warmups) if w >= first_warmup), len(self.warmups) - 1)
-        self._ladder_fv, self._ladder_fr, self._ladder_bwd = (_WarmupLadder(self.warmups, start) for _ in range(3))
+        self._ladder_fv, self._ladder_fr, self._ladder_bwd, self._ladder_rb = (
+            _WarmupLadder(self.warmups, start) for _ in range(4))   # value fwd, reward fwd, value bwd, reward bwd
         self.last_seam = None
         self._ws = {}
         self._side = None
@@ -255,7 +256,7 @@ class A2CEngine:
 
     def _segments_for(self, positions):
         """Number of segments for a chain of `positions` steps; 0 = use the exact kernels."""
-        if self.chain_mode == "exact" or (self.chain_mode == "auto" and positions < 8192):
+        if self.chain_mode == "exact" or (self.chain_mode == "auto" and positions < 4096):
             return 0
         if self.segments:
             return int(self.segments)
@@ -369,21 +370,57 @@ class A2CEngine:
         hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, p0 * n, ws["Xv"])
         hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
                  bias2=V["valrnn.lstm.bias_hh_l0"])
-        hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, 1, ws["hv"], ws["saved"], ws["sync_v"],
-                           ws["status"][0:1])
-        w1 = V["linear1.weight"]
-        hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
-        hip.gemm(ws["hv"].view(n, H), w1[:, self.F:], ws["Y"])
-        hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], n, n, ws["values"])
-        hip.mse_loss(ws["values"], targets, ws["scalars"][0:1], ws["dvalue"])
-        self._value_head_backward(ws, features, n, 1)
-        hip.chain_hprev(ws["saved"], ws["tv"], ws["hprev"])
-        self._value_chain_backward(ws, n, p0, 1, main, main, ("exact",), None)
+        # the chain starts from zeros (the loop resets the state every minibatch), so a long one runs
+        # segment-parallel under the same seam checks and warm-up ladders as the A2C step
+        plans = self._plans(ws)
+        last = len(plans) - 1
+        fv, bi = min(self._ladder_fv.first, last), min(self._ladder_bwd.first, last)
+        redo_forward = True
+        while True:
+            pv = plans[fv]
+            if pv[0] == "exact":
+                bi = last
+            pb = plans[bi]
+            if redo_forward:
+                if pv[0] == "segmented":
+                    hip.lstm_chain_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, 1, pv[1], pv[2], ws["hv"],
+                                           ws["saved"], ws["work_v"], ws["seam"][0:2])
+                else:
+                    hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, 1, ws["hv"], ws["saved"],
+                                       ws["sync_v"], ws["status"][0:1])
+                w1 = V["linear1.weight"]
+                hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
+                hip.gemm(ws["hv"].view(n, H), w1[:, self.F:], ws["Y"])
+                hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], n, n, ws["values"])
+                hip.mse_loss(ws["values"], targets, ws["scalars"][0:1], ws["dvalue"])
+                self._value_head_backward(ws, features, n, 1)
+                hip.chain_hprev(ws["saved"], ws["tv"], ws["hprev"])
+            self._value_chain_backward(ws, n, p0, 1, main, main, pb, None)
+            seg_v, seg_b = pv[0] == "segmented", pb[0] == "segmented"
+            if not (seg_v or seg_b):
+                break
+            seam = ws["seam"].tolist()
+            self.last_seam = seam
+            checks_v = [(seam[0], self.SEAM_TOL_FWD)] if seg_v else []
+            checks_b = [(seam[4] / seam[5] if seam[5] > 0 else 0.0, self.SEAM_TOL_BWD)] if seg_b else []
+            ok_v, ok_b = all(e <= t for e, t in checks_v), all(e <= t for e, t in checks_b)
+            if ok_v and ok_b:
+                self._ladder_fv.accepted(fv, checks_v, last)
+                self._ladder_bwd.accepted(bi, checks_b, last)
+                break
+            self.fallbacks += 1
+            redo_forward = not ok_v
+            if not ok_v:
+                fv = self._next_plan(plans, fv, checks_v)
+                self._ladder_fv.rejected(fv)
+            if not ok_b:
+                bi = self._next_plan(plans, bi, checks_b)
+                self._ladder_bwd.rejected(bi)
         return ws["scalars"][0:1], ws["values"]
 
     def reward_vse_step(self, features, captions, beta=0.2):
         """One minibatch of the reward pre-training loop (trainers.py:286-300): the GRU chain over the
-        whole captions [N, L] (walked exactly, activations kept), the two embeddings,
+        whole captions [N, L] (activations kept; segment-parallel when long enough), the two embeddings,
         VisualSemanticEmbeddingLoss on their [N, N] similarity matrix, and the gradients of every reward
         network parameter (BPTT through the batch-1 chain included).  Returns the loss (1-element tensor)."""
         R, gR = self.R, self.gR
@@ -402,7 +439,10 @@ class A2CEngine:
                       dve=f32(n, 512), d_emit=f32(1, n, H), dgx=f32(pos, 3 * H), dgh=f32(pos, 3 * H), hprev=f32(pos, H),
                       dX=f32(pos, er), scratch=f32(max(16 * 3 * H * H, 16 * 512 * max(512, self.F))),
                       sync=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
-                      status=torch.zeros(4, dtype=torch.int32, device=dev))
+                      status=torch.zeros(4, dtype=torch.int32, device=dev),
+                      seam=torch.zeros(6, dtype=torch.float32, device=dev), segments=self._segments_for(pos))
+            if ws["segments"]:
+                ws["work"] = f32(hip.chain_seg_workspace_floats(ws["segments"]))
             self._ws[key] = ws
         ws["tok"].copy_(captions.t())
         tok = ws["tok"].view(-1)
@@ -410,8 +450,47 @@ class A2CEngine:
         # ---- forward
         hip.gather_rows(R["rewrnn.caption_embedding.weight"], tok, 1, pos, ws["X"])
         hip.gemm(ws["X"], w_ih, ws["XP"], bias=R["rewrnn.gru.bias_ih_l0"])
-        hip.gru_chain_fwd(ws["XP"], w_hh, R["rewrnn.gru.bias_hh_l0"], n, l_cols, 1, ws["hr"], ws["sync"],
-                          ws["status"][0:1], saved=ws["saved"])
+        # the chain starts from zeros, so a long one runs segment-parallel, forward and backward, under the
+        # same seam checks and warm-up ladders as the A2C step (a rejected attempt is redone)
+        plans = self._plans(ws)
+        last = len(plans) - 1
+        fr, rb = min(self._ladder_fr.first, last), min(self._ladder_rb.first, last)
+        while True:
+            pf, pb = plans[fr], plans[rb]
+            self._reward_vse_attempt(ws, features, n, l_cols, beta, tok, pf, pb)
+            seg_f, seg_b = pf[0] == "segmented", pb[0] == "segmented"
+            if not (seg_f or seg_b):
+                break
+            seam = ws["seam"].tolist()
+            self.last_seam = seam
+            checks_f = [(seam[2], self.SEAM_TOL_FWD)] if seg_f else []
+            checks_b = [(seam[4] / seam[5] if seam[5] > 0 else 0.0, self.SEAM_TOL_BWD)] if seg_b else []
+            ok_f, ok_b = all(e <= t for e, t in checks_f), all(e <= t for e, t in checks_b)
+            if ok_f and ok_b:
+                self._ladder_fr.accepted(fr, checks_f, last)
+                self._ladder_rb.accepted(rb, checks_b, last)
+                break
+            self.fallbacks += 1
+            if not ok_f:
+                fr = self._next_plan(plans, fr, checks_f)
+                self._ladder_fr.rejected(fr)
+            if not ok_b:
+                rb = self._next_plan(plans, rb, checks_b)
+                self._ladder_rb.rejected(rb)
+        self._vse_status = ws["status"]
+        return ws["loss"]
+
+    def _reward_vse_attempt(self, ws, features, n, l_cols, beta, tok, plan_f, plan_b):
+        """Everything of reward_vse_step after the input projection, with the chain run as the plans say."""
+        R, gR = self.R, self.gR
+        pos = n * l_cols
+        w_ih, w_hh = R["rewrnn.gru.weight_ih_l0"], R["rewrnn.gru.weight_hh_l0"]
+        if plan_f[0] == "segmented":
+            hip.gru_chain_fwd_seg(ws["XP"], w_hh, R["rewrnn.gru.bias_hh_l0"], n, l_cols, 1, plan_f[1], plan_f[2],
+                                  ws["hr"], ws["work"], ws["seam"][2:4], saved=ws["saved"])
+        else:
+            hip.gru_chain_fwd(ws["XP"], w_hh, R["rewrnn.gru.bias_hh_l0"], n, l_cols, 1, ws["hr"], ws["sync"],
+                              ws["status"][0:1], saved=ws["saved"])
         hr = ws["hr"].view(n, H)
         hip.gemm(hr, R["semantic_embed.weight"], ws["se"], bias=R["semantic_embed.bias"])
         hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
@@ -427,8 +506,12 @@ class A2CEngine:
         hip.colsum(ws["dse"], gR["semantic_embed.bias"])
         hip.gemm(ws["dse"], R["semantic_embed.weight"], ws["d_emit"].view(n, H), b_kmajor=True)
         # ---- backward: the chain, then its weight gradients as products over all positions
-        hip.gru_chain_bwd(w_hh, ws["saved"], ws["d_emit"], n, l_cols, 1, ws["dgx"], ws["dgh"], ws["sync"],
-                          ws["status"][1:2])
+        if plan_b[0] == "segmented":
+            hip.gru_chain_bwd_seg(w_hh, ws["saved"], ws["d_emit"], n, l_cols, 1, plan_b[1], plan_b[2], ws["dgx"],
+                                  ws["dgh"], ws["work"], ws["seam"][4:6])
+        else:
+            hip.gru_chain_bwd(w_hh, ws["saved"], ws["d_emit"], n, l_cols, 1, ws["dgx"], ws["dgh"], ws["sync"],
+                              ws["status"][1:2])
         hip.chain_hprev(ws["saved"], pos, ws["hprev"], gru=True)
         hip.gemm_auto(ws["dgh"], ws["hprev"], gR["rewrnn.gru.weight_hh_l0"], sc, a_kmajor=True, b_kmajor=True)
         hip.colsum(ws["dgh"], gR["rewrnn.gru.bias_hh_l0"])
@@ -439,8 +522,6 @@ class A2CEngine:
             hip.gemm_auto(ws["dgx"], w_ih, ws["dX"], sc, b_kmajor=True)
             g_emb.zero_()
             hip.scatter_add_rows(g_emb, tok, 1, pos, ws["dX"])
-        self._vse_status = ws["status"]
-        return ws["loss"]
 
     # ------------------------------------------------------------------ the step
     def step(self, features, prefix, n_steps, uniforms=None, forced_tokens=None, mode=hip.SAMPLE, backward=True):

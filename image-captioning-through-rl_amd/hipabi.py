@@ -34,7 +34,8 @@ SIGNATURES = {
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 7 + [c_vp] * 8),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
     "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
@@ -408,12 +409,18 @@ def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, sa
     _check(rc, "icrl_lstm_chain_fwd_seg")
 
 
-def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err):
+def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err, saved=None):
     with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_gru_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
-                                           segments, warmup, _ptr(_f32c(h_emit)), _ptr(_f32c(work)), _ptr(seam_err),
-                                           _stream())
+                                           segments, warmup, _ptr(_f32c(h_emit)), _ptr(saved), _ptr(_f32c(work)),
+                                           _ptr(seam_err), _stream())
     _check(rc, "icrl_gru_chain_fwd_seg")
+
+
+def gru_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates_x, dgates_h, work, seam_err):
+    _check(load().icrl_gru_chain_bwd_seg(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
+                                         segments, warmup, _ptr(_f32c(dgates_x)), _ptr(_f32c(dgates_h)),
+                                         _ptr(_f32c(work)), _ptr(seam_err), _stream()), "icrl_gru_chain_bwd_seg")
 
 
 def chain_pair_supported(segments):

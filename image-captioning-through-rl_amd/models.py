@@ -22,6 +22,12 @@ MAX_SEQ_LEN = 17  # the max captions len in the dataset (models.py:18)
 H = 512
 
 
+# segment-parallel evaluation of a recurrence that starts from zeros (see RewardNetworkRNN._forward_segmented)
+SEGMENTED_MIN_POSITIONS = 4096
+SEGMENTED_WARMUPS = (96, 192, 384, 768)
+SEGMENTED_SEAM_TOL = 1e-5
+
+
 def repackage_hidden(h):
     """Detach hidden states from their history (models.py:20-30)."""
     if isinstance(h, torch.Tensor):
@@ -211,6 +217,7 @@ class RewardNetworkRNN(nn.Module):
         self.hidden_dim = hidden_dim
         self.per_sample = per_sample   # one recurrent state per row, as in ValueNetworkRNN
         self._row_state = None
+        self._seg_work, self._seg_err, self._seg_warmup = None, None, 0
         self.word_to_idx = word_to_idx
         self.idx_to_word = {i: w for w, i in word_to_idx.items()}
         self.caption_embedding, wordvec_dim = _embedding(len(word_to_idx), wordvec_dim, pretrained_embeddings)
@@ -218,9 +225,19 @@ class RewardNetworkRNN(nn.Module):
         self.gru = nn.GRU(wordvec_dim, hidden_dim, bidirectional=False)
         self._chain_ws = _ChainWorkspace()
 
+    @property
+    def hidden_cell(self):
+        return self._hidden_cell
+
+    @hidden_cell.setter
+    def hidden_cell(self, value):   # a state assigned from outside is not known to be zeros
+        self._hidden_cell = value
+        self._fresh = False
+
     def init_hidden(self):
         self.hidden_cell = torch.zeros(1, 1, self.hidden_dim).to(device)
         self._row_state = None
+        self._fresh = True   # the state is zeros: a long chain may run segment-parallel
 
     @torch.no_grad()
     def forward_columns(self, tok_t):
@@ -242,9 +259,13 @@ class RewardNetworkRNN(nn.Module):
             self._row_state = h
             self.hidden_cell = h.view(1, n, H)
             return h
+        h_emit = torch.empty(1, n, H, device=dev)
+        fresh, self._fresh = self._fresh, False
+        if fresh and p * n >= SEGMENTED_MIN_POSITIONS and self._forward_segmented(xproj, n, p, h_emit):
+            self.hidden_cell = h_emit[0, n - 1].view(1, 1, H).clone()
+            return h_emit[0]
         state = self.hidden_cell.reshape(-1).to(dev).contiguous()
         state_out = torch.empty_like(state)
-        h_emit = torch.empty(1, n, H, device=dev)
         sync, status = self._chain_ws.get(dev)
         hip.gru_chain_fwd(xproj, self.gru.weight_hh_l0, self.gru.bias_hh_l0, n, p, 1, h_emit, sync, status,
                           state_in=state, state_out=state_out)
@@ -252,6 +273,24 @@ class RewardNetworkRNN(nn.Module):
             raise RuntimeError("reward GRU chain kernel timed out")
         self.hidden_cell = state_out.view(1, 1, H)
         return h_emit[0]
+
+    def _forward_segmented(self, xproj, n, p, h_emit):
+        """A chain that starts from zeros, cut into segments that run side by side after a warm-up
+        (icrl_gru_chain_fwd_seg).  Accepted only if every segment's warmed-up state met the state its
+        neighbour really ended in to rounding; the warm-up that passed is tried first next time.
+        False: no warm-up length passed, the caller walks the chain exactly."""
+        dev = xproj.device
+        segments = max(32, min(512, p * n // 16 // 32 * 32))
+        if self._seg_work is None or self._seg_work.numel() < hip.chain_seg_workspace_floats(segments):
+            self._seg_work = torch.empty(hip.chain_seg_workspace_floats(segments), device=dev)
+            self._seg_err = torch.zeros(2, device=dev)
+        for warmup in (w for w in SEGMENTED_WARMUPS if w >= self._seg_warmup):
+            hip.gru_chain_fwd_seg(xproj, self.gru.weight_hh_l0, self.gru.bias_hh_l0, n, p, 1, segments, warmup, h_emit,
+                                  self._seg_work, self._seg_err)
+            if self._seg_err[0].item() <= SEGMENTED_SEAM_TOL:
+                self._seg_warmup = warmup
+                return True
+        return False
 
     def forward(self, captions):
         caps = torch.as_tensor(captions, device=self.gru.weight_hh_l0.device).long()

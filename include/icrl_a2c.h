@@ -193,9 +193,18 @@ int64_t icrl_chain_seg_workspace_floats(int segments);
 int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
                             int segments, int warmup, float* h_emit, float* saved, float* work,
                             float* seam_err, icrl_stream_t stream);
+/* saved (may be NULL): the GRU chain's activations {r, z, n, hn, h}, 5*512 floats per position, as
+ * icrl_gru_chain_fwd keeps them for icrl_gru_chain_bwd. */
 int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                           int n_calls, int segments, int warmup, float* h_emit, float* work,
-                           float* seam_err, icrl_stream_t stream);
+                           int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                           float* work, float* seam_err, icrl_stream_t stream);
+/* icrl_gru_chain_bwd (the BPTT through RewardNetworkRNN's recurrence, trainers.py:288-300) evaluated
+ * segment-parallel: same inputs, outputs and layouts; seam_err as for icrl_lstm_chain_bwd_seg
+ * (seam_err[0] = max |a-b|, seam_err[1] = max |b| over the product W_hh^T dgates_h and the carried
+ * dh*z at the seams). */
+int icrl_gru_chain_bwd_seg(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                           int n_calls, int segments, int warmup, float* dgates_x, float* dgates_h,
+                           float* work, float* seam_err, icrl_stream_t stream);
 int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
                             int n_calls, int segments, int warmup, float* dgates, float* work,
                             float* seam_err, icrl_stream_t stream);

@@ -515,3 +515,83 @@ def test_seam_check_rejects_and_falls_back_to_the_exact_kernels():
     for k in g_exact:
         scale = g_exact[k].pow(2).mean().sqrt().item() + 1e-12
         assert (g_seg[k] - g_exact[k]).abs().max().item() <= 1e-4 * scale + 1e-9, k
+
+
+def test_reward_module_runs_a_long_fresh_chain_segment_parallel_and_agrees_with_the_exact_walk():
+    """GetRewards on a whole minibatch right after init_hidden(): 300 rows x 17 columns is long enough for
+    the segment-parallel kernels; a second call (state no longer zeros) walks exactly.  Both must equal the
+    exact walk of the same chains."""
+    cfg = dict(n=300, vocab=400, caplen=17, fdim=512, seed=9, level=None)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(300, 400, 17, 512, 9)
+    f, c = torch.from_numpy(feats).cuda(), torch.from_numpy(caps).cuda()
+    rew.rewrnn.init_hidden()
+    assert rew.rewrnn._fresh
+    r1 = trainers.GetRewards(f, c, rew)
+    assert rew.rewrnn._seg_warmup > 0 and not rew.rewrnn._fresh       # the segmented path ran and was accepted
+    r2 = trainers.GetRewards(f, c, rew)                               # continues from the first call's state
+    models_mod = importlib.import_module("image-captioning-through-rl_amd.models")
+    saved = models_mod.SEGMENTED_MIN_POSITIONS
+    try:
+        models_mod.SEGMENTED_MIN_POSITIONS = 1 << 30                 # force the exact walk
+        rew.rewrnn.init_hidden()
+        e1 = trainers.GetRewards(f, c, rew)
+        e2 = trainers.GetRewards(f, c, rew)
+    finally:
+        models_mod.SEGMENTED_MIN_POSITIONS = saved
+    np.testing.assert_allclose(r1.cpu().numpy(), e1.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(r2.cpu().numpy(), e2.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_value_pretraining_step_segment_parallel_equals_the_exact_walk():
+    """value_mse_step on 512 rows x 9 columns (4608 positions: long enough for the segment-parallel
+    kernels) against the same step on the exact chain kernels: loss, values and every gradient."""
+    engine_mod = importlib.import_module("image-captioning-through-rl_amd.engine")
+    cfg = dict(n=512, vocab=300, caplen=12, fdim=512, seed=13, level=None)
+    a2c, _ = build_modules(cfg)
+    val = a2c.value_network
+    feats, caps = synthetic.make_minibatch(512, 300, 12, 512, 13)
+    f, c = torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :9]).cuda().contiguous()
+    targets = torch.from_numpy(np.random.RandomState(3).uniform(-1, 1, 512).astype(np.float32)).cuda()
+    out = {}
+    for mode in ("exact", "auto"):
+        eng = engine_mod.A2CEngine(None, trainers._params_of(val), None, None, trainers._grads_of(val), chain_mode=mode)
+        loss, values = eng.value_mse_step(f, c, targets)
+        torch.cuda.synchronize()
+        assert int(eng._buffers(512, 9, 1)["status"].abs().sum()) == 0
+        out[mode] = (loss.item(), values.clone(), {k: p.grad.clone() for k, p in val.named_parameters()}, eng)
+    assert out["auto"][3].fallbacks == 0 and out["auto"][3].last_seam is not None   # segmented, accepted at once
+    assert out["auto"][0] == pytest.approx(out["exact"][0], rel=1e-5)
+    np.testing.assert_allclose(out["auto"][1].cpu().numpy(), out["exact"][1].cpu().numpy(), rtol=1e-5, atol=2e-6)
+    for k, g in out["exact"][2].items():
+        scale = g.pow(2).mean().sqrt().item() + 1e-12
+        assert (out["auto"][2][k] - g).abs().max().item() <= 1e-3 * scale + 1e-9, k
+
+
+def test_reward_pretraining_step_segment_parallel_equals_the_exact_walk():
+    """reward_vse_step on 512 rows x 17 columns (8704 positions) with the GRU chain segment-parallel forward
+    and backward, against the same step on the exact chain kernels: loss and every gradient."""
+    engine_mod = importlib.import_module("image-captioning-through-rl_amd.engine")
+    cfg = dict(n=512, vocab=300, caplen=17, fdim=512, seed=17, level=None)
+    _, rew = build_modules(cfg)
+    rew.requires_grad_(True)
+    for p in rew.parameters():
+        p.grad = torch.zeros_like(p)
+    feats, caps = synthetic.make_minibatch(512, 300, 17, 512, 17)
+    f, c = torch.from_numpy(feats).cuda(), torch.from_numpy(caps).cuda()
+    out = {}
+    for mode in ("exact", "auto"):
+        eng = engine_mod.A2CEngine(None, None, trainers._params_of(rew), reward_grads=trainers._grads_of(rew),
+                                   chain_mode=mode)
+        loss = eng.reward_vse_step(f, c)
+        torch.cuda.synchronize()
+        assert int(eng._vse_status.abs().sum()) == 0
+        out[mode] = (loss.item(), {k: p.grad.clone() for k, p in rew.named_parameters()}, eng)
+    assert out["auto"][2].fallbacks == 0 and out["auto"][2].last_seam is not None
+    assert out["auto"][0] == pytest.approx(out["exact"][0], rel=1e-5)
+    # the loss is a sum of 2 x 512 x 511 hinges: a similarity that differs in its last bits can switch one on
+    # or off, and each switch moves the gradients by a 512th of an embedding, so they are compared loosely
+    # here (the chain kernels themselves are held to 1e-4 in test_gpu_kernels.py)
+    for k, g in out["exact"][1].items():
+        scale = g.pow(2).mean().sqrt().item() + 1e-12
+        assert (out["auto"][1][k] - g).abs().max().item() <= 5e-2 * scale + 1e-9, k

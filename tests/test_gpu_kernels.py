@@ -491,3 +491,34 @@ def test_gru_chain_backward_and_vse_loss_match_autograd():
     want.backward()
     assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item())
     np.testing.assert_allclose(dS.cpu().numpy(), St.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,p0,calls,segs,warm", [(64, 17, 1, 32, 64), (48, 2, 7, 9, 48), (512, 17, 1, 512, 64)])
+def test_segmented_gru_forward_keeps_activations_and_backward_matches_the_exact_kernels(n, p0, calls, segs, warm):
+    """The reward GRU chain segment-parallel, forward with its activations kept and backward, against the
+    exact kernels on the same inputs: {r, z, n, hn, h} per position, emitted h, both gate-gradient streams."""
+    rs = np.random.RandomState(100 + segs)
+    cols = p0 + calls - 1
+    pos = n * sum(p0 + s for s in range(calls))
+    xproj, w_hh = _chain_inputs(rs, n, cols, 3)
+    xd, wd, bd = dev(xproj), dev(w_hh), dev(rnd(rs, 3 * H, scale=0.1))
+    d_emit = dev(rnd(rs, calls, n, H, scale=0.01))
+    ws, status = _ws()
+    h_x, saved_x = torch.zeros(calls, n, H, device="cuda"), torch.zeros(pos, 5, H, device="cuda")
+    gx_x, gh_x = torch.zeros(pos, 3 * H, device="cuda"), torch.zeros(pos, 3 * H, device="cuda")
+    hip.gru_chain_fwd(xd, wd, bd, n, p0, calls, h_x, ws, status, saved=saved_x)
+    hip.gru_chain_bwd(wd, saved_x, d_emit, n, p0, calls, gx_x, gh_x, ws, status)
+    work, err_f = _seg_ws(segs)
+    err_b = torch.zeros(2, device="cuda")
+    h_s, saved_s = torch.zeros_like(h_x), torch.full_like(saved_x, float("nan"))
+    gx_s, gh_s = torch.full_like(gx_x, float("nan")), torch.full_like(gh_x, float("nan"))
+    hip.gru_chain_fwd_seg(xd, wd, bd, n, p0, calls, segs, warm, h_s, work, err_f, saved=saved_s)
+    hip.gru_chain_bwd_seg(wd, saved_s, d_emit, n, p0, calls, segs, warm, gx_s, gh_s, work, err_b)
+    torch.cuda.synchronize()
+    assert status.item() == 0 and err_f[0].item() < 2e-6
+    assert err_b[0].item() <= 1e-4 * err_b[1].item()
+    np.testing.assert_allclose(h_s.cpu().numpy(), h_x.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(saved_s.cpu().numpy(), saved_x.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    for got, want in ((gx_s, gx_x), (gh_s, gh_x)):
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() <= 1e-4 * scale, ((got - want).abs().max().item(), scale)
