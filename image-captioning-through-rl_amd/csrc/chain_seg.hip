@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
                                                        const float* __restrict__ c_cur, float* __restrict__ c_nxt,
                                                        float* __restrict__ h_nxt, float* __restrict__ saved,
                                                        float* __restrict__ h_emit, float* __restrict__ seam_a,
-                                                       float* __restrict__ seam_b, Geom g, int m) {
+                                                       float* __restrict__ seam_b, const float* __restrict__ state_in,
+                                                       Geom g, int m) {
     constexpr int NT = 256;                    // threads
     constexpr int ROWS = 32 + G * 32;          // stage rows: 32 of H, then G x 32 of W_hh
     constexpr int F4 = ROWS * (BK / 4);        // float4 per stage
@@ -275,8 +276,16 @@ __global__ __launch_bounds__(256) void seg_fwd_step(const float* __restrict__ h_
         const int qs = m - g.W;     // step within the segment: negative during the warm-up
         const int64_t pos = it_pos[ii];
         if (it_state[ii] == 1) {
-            st4(h_nxt + (int64_t)j * H + u, zero4());
-            if (G == 4) st4(c_nxt + (int64_t)j * H + u, zero4());
+            // outside the segment's range the state is zero - except that the chain itself may start from a
+            // given state {h, c}: every segment whose warm-up reaches back to the chain's start picks it up on
+            // the step before position 0, and is exact from there
+            float4 h0 = zero4(), c0 = zero4();
+            if (state_in && pos == -1) {
+                h0 = ld4(state_in + u);
+                if (G == 4) c0 = ld4(state_in + H + u);
+            }
+            st4(h_nxt + (int64_t)j * H + u, h0);
+            if (G == 4) st4(c_nxt + (int64_t)j * H + u, c0);
             continue;
         }
         const int s = it_s[ii], t = it_t[ii], i = it_i[ii];
@@ -1106,7 +1115,7 @@ __global__ void flag_on_abort(const unsigned* abort_w, int* status) {
 //   backward     : dgates[2][4 kh], dc[kh], seam_a[2 kh], dh_fin[kh]
 //   all          : polled words of the persistent launches from 12 kh
 int fwd_steps_lstm(const Geom& g, const float* xproj, const float* w_hh, float* h_emit, float* saved, float* work,
-                    hipStream_t st) {
+                    const float* state_in, hipStream_t st) {
     const int64_t kh = (int64_t)g.K * H;
     float* hb[2] = {work, work + kh};
     float* cb[2] = {work + 2 * kh, work + 3 * kh};
@@ -1115,7 +1124,7 @@ int fwd_steps_lstm(const Geom& g, const float* xproj, const float* w_hh, float* 
     for (int m = 0; m < g.W + g.Ls; ++m) {
         const int cur = m & 1;
         hipLaunchKernelGGL(seg_fwd_step<4>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, (const float*)nullptr,
-                           cb[cur], cb[cur ^ 1], hb[cur ^ 1], saved, h_emit, work + 4 * kh, work + 6 * kh, g, m);
+                           cb[cur], cb[cur ^ 1], hb[cur ^ 1], saved, h_emit, work + 4 * kh, work + 6 * kh, state_in, g, m);
     }
     return ICRL_OK;
 }
@@ -1129,7 +1138,8 @@ int fwd_steps_gru(const Geom& g, const float* xproj, const float* w_hh, const fl
     for (int m = 0; m < g.W + g.Ls; ++m) {
         const int cur = m & 1;
         hipLaunchKernelGGL(seg_fwd_step<3>, grid, dim3(256), 0, st, hb[cur], w_hh, xproj, b_hh, (const float*)nullptr,
-                           (float*)nullptr, hb[cur ^ 1], saved, h_emit, work + 2 * kh, work + 3 * kh, g, m);
+                           (float*)nullptr, hb[cur ^ 1], saved, h_emit, work + 2 * kh, work + 3 * kh,
+                           (const float*)nullptr, g, m);
     }
     return ICRL_OK;
 }
@@ -1191,8 +1201,8 @@ int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out) {
 extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64_t)segments * 16 * H; }
 
 extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
-                                       int segments, int warmup, float* h_emit, float* saved, float* work,
-                                       float* seam_err, icrl_stream_t stream) {
+                                       int segments, int warmup, float* h_emit, float* saved,
+                                       const float* state_in, float* work, float* seam_err, icrl_stream_t stream) {
     Geom g;
     if (int rc = make_geom("icrl_lstm_chain_fwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && h_emit && work && seam_err, "icrl_lstm_chain_fwd_seg: null pointer");
@@ -1201,7 +1211,8 @@ extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, in
     hipStream_t st = icrl::as_stream(stream);
     const int64_t kh = (int64_t)g.K * H;
     ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
-    if (int rc = fwd_steps_lstm(g, xproj, w_hh, h_emit, saved, work, st)) return rc;
+    ICRL_REQUIRE(aligned16(state_in), "icrl_lstm_chain_fwd_seg: buffers must be 16-byte aligned");
+    if (int rc = fwd_steps_lstm(g, xproj, w_hh, h_emit, saved, work, state_in, st)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, work + 4 * kh, work + 6 * kh,
                        g, 2 * H, seam_err);
     ICRL_LAUNCH_CHECK();
@@ -1365,7 +1376,7 @@ extern "C" int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_
         if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
         hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
     } else {
-        if (int rc = fwd_steps_lstm(v.g, xproj_v, w_hh_v, h_emit_v, saved_v, work_v, st)) return rc;
+        if (int rc = fwd_steps_lstm(v.g, xproj_v, w_hh_v, h_emit_v, saved_v, work_v, nullptr, st)) return rc;
         if (int rc = fwd_steps_gru(r.g, xproj_r, w_hh_r, b_hh_r, h_emit_r, nullptr, work_r, st)) return rc;
     }
     ICRL_LAUNCH_CHECK();

@@ -25,7 +25,7 @@ SIGNATURES = {
                                      c_int, c_int, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
-    "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_masked_nll": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_mse_loss": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -401,11 +401,12 @@ def chain_seg_workspace_floats(segments):
     return int(load().icrl_chain_seg_workspace_floats(segments))
 
 
-def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, work, seam_err):
+def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, work, seam_err, state_in=None):
+    """state_in: {h, c} (1024 floats) the chain starts from; None = zeros."""
     with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_lstm_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, segments, warmup,
-                                            _ptr(_f32c(h_emit)), _ptr(saved), _ptr(_f32c(work)), _ptr(seam_err),
-                                            _stream())
+                                            _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(_f32c(work)),
+                                            _ptr(seam_err), _stream())
     _check(rc, "icrl_lstm_chain_fwd_seg")
 
 

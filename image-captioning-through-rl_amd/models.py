@@ -123,6 +123,7 @@ class ValueNetworkRNN(nn.Module):
         # reference computes when it is called with one image at a time.  Never a default.
         self.per_sample = per_sample
         self._row_state = None
+        self._seg_work, self._seg_err, self._seg_warmup = None, None, 0
         self.word_to_idx = word_to_idx
         self.idx_to_word = {i: w for w, i in word_to_idx.items()}
         self.caption_embedding, wordvec_dim = _embedding(len(word_to_idx), wordvec_dim, pretrained_embeddings)
@@ -168,6 +169,48 @@ class ValueNetworkRNN(nn.Module):
         self.hidden_cell = (state_out[:H].view(1, 1, H), state_out[H:].view(1, 1, H))
         return h_emit[0]
 
+    @torch.no_grad()
+    def forward_columns_many(self, tok_list):
+        """Several forward_columns calls in a row (each tok [p, N]; the state runs through all of them, as
+        it does when the decoder scores one candidate extension after the other) as ONE chain: the calls'
+        columns are stacked, the chain keeps every position's h, and each call's last column is read back
+        from there.  Long chains run segment-parallel from the carried state, under the seam check.
+        Returns the list of [N, H] outputs."""
+        if self.per_sample:
+            return [self.forward_columns(tok) for tok in tok_list]
+        dev = self.lstm.weight_hh_l0.device
+        p, n = tok_list[0].shape
+        calls = len(tok_list)
+        tok_all = torch.cat([tok.reshape(-1) for tok in tok_list])
+        positions = calls * p * n
+        xproj = torch.empty(positions, 4 * H, device=dev)
+        hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, xproj, a_rows=tok_all,
+                 bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
+        state = torch.cat((self.hidden_cell[0].reshape(-1), self.hidden_cell[1].reshape(-1))).to(dev).contiguous()
+        saved = torch.empty(positions, 6, H, device=dev)
+        h_emit = torch.empty(1, n, H, device=dev)
+        done = False
+        if positions >= SEGMENTED_MIN_POSITIONS:
+            segments = max(32, min(512, positions // 16 // 32 * 32))
+            if self._seg_work is None or self._seg_work.numel() < hip.chain_seg_workspace_floats(segments):
+                self._seg_work = torch.empty(hip.chain_seg_workspace_floats(segments), device=dev)
+                self._seg_err = torch.zeros(2, device=dev)
+            for warmup in (w for w in SEGMENTED_WARMUPS if w >= self._seg_warmup):
+                hip.lstm_chain_fwd_seg(xproj, self.lstm.weight_hh_l0, n, calls * p, 1, segments, warmup, h_emit, saved,
+                                       self._seg_work, self._seg_err, state_in=state)
+                if self._seg_err[0].item() <= SEGMENTED_SEAM_TOL:
+                    self._seg_warmup, done = warmup, True
+                    break
+        if not done:
+            sync, status = self._chain_ws.get(dev)
+            hip.lstm_chain_fwd(xproj, self.lstm.weight_hh_l0, n, calls * p, 1, h_emit, saved, sync, status,
+                               state_in=state, state_out=torch.empty_like(state))
+            if status.item() != 0:
+                raise RuntimeError("value LSTM chain kernel timed out")
+        self.hidden_cell = (saved[-1, 5].view(1, 1, H).clone(), saved[-1, 4].view(1, 1, H).clone())
+        by_call = saved.view(calls, p, n, 6, H)
+        return [by_call[c, p - 1, :, 5, :].contiguous() for c in range(calls)]
+
     def forward(self, captions):
         """captions [N] -> [N,1,H] (models.py:130-135)."""
         caps = torch.as_tensor(captions, device=self.lstm.weight_hh_l0.device).long()
@@ -203,6 +246,26 @@ class ValueNetwork(nn.Module):
         values = torch.empty(n, device=dev)
         hip.value_head_fwd(y, u, self.linear2.weight, self.linear2.bias, n, n, values)
         return values.view(n, 1)
+
+
+    @torch.no_grad()
+    def forward_many(self, features, captions_list):
+        """forward(features, c) for every c of captions_list (equal shapes [N,p]) in that order, the
+        recurrent state running through all of them, with the calls' chains joined into one launch
+        sequence (ValueNetworkRNN.forward_columns_many).  Returns the list of [N,1] values."""
+        dev = self.linear1.weight.device
+        feats = _dev_f32(features, dev)
+        n, f = feats.shape
+        toks = [torch.as_tensor(c, device=dev).long().t().contiguous() for c in captions_list]
+        u = torch.empty(n, 512, device=dev)
+        hip.gemm(feats, self.linear1.weight[:, :f], u, bias=self.linear1.bias)
+        out = []
+        for hs in self.valrnn.forward_columns_many(toks):
+            y, values = torch.empty(n, 512, device=dev), torch.empty(n, device=dev)
+            hip.gemm(hs, self.linear1.weight[:, f:], y)
+            hip.value_head_fwd(y, u, self.linear2.weight, self.linear2.bias, n, n, values)
+            out.append(values.view(n, 1))
+        return out
 
 
 class RewardNetworkRNN(nn.Module):

@@ -93,15 +93,20 @@ def GenerateCaptionsWithActorCriticLookAhead(features, captions, policy_network,
     gen_caps = torch.as_tensor(caps0, device=dev).long()
     candidates = [(gen_caps, 0)]
     for _ in range(MAX_SEQ_LEN - 1):
-        next_candidates = []
+        # the policy network is stateless, so all extensions of a step are known before the value network
+        # sees the first of them; it then scores them in the reference's order (candidate by candidate,
+        # word by word, its state running through), as one chain
+        extensions = []
         for cand, cand_score in candidates:
             logits = policy_network(feats.unsqueeze(0), cand)[:, -1, :].contiguous()
             top_vals, top_words = hip.topk_rows(logits, beamSize)
             for i in range(beamSize):
-                cap = torch.cat((cand, top_words[:, i:i + 1]), dim=1)
-                value = value_network(feats, cap)
-                score_delta = 0.6 * value + 0.4 * torch.log(top_vals[:, i:i + 1])
-                next_candidates.append((cap, cand_score - score_delta))
+                extensions.append((torch.cat((cand, top_words[:, i:i + 1]), dim=1), cand_score, top_vals[:, i:i + 1]))
+        values = value_network.forward_many(feats, [e[0] for e in extensions])
+        next_candidates = []
+        for (cap, cand_score, top_val), value in zip(extensions, values):
+            score_delta = 0.6 * value + 0.4 * torch.log(top_val)
+            next_candidates.append((cap, cand_score - score_delta))
         means = [float(c[1].mean()) for c in next_candidates]       # one read-back per candidate
         order = sorted(range(len(next_candidates)), key=lambda j: means[j])
         candidates = [next_candidates[j] for j in order[:beamSize]]

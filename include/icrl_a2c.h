@@ -188,11 +188,13 @@ int icrl_gru_chain_bwd(const float* w_hh, const float* saved, const float* d_emi
  * over dh and dc).  The caller accepts the result only when that is at rounding level and
  * otherwise reruns with a longer warm-up or the exact kernels above.  Same inputs,
  * outputs and layouts as icrl_lstm_chain_fwd / icrl_gru_chain_fwd / icrl_lstm_chain_bwd
- * (zero initial state); work = icrl_chain_seg_workspace_floats(segments) floats. */
+ * (zero initial state; icrl_lstm_chain_fwd_seg also takes state_in = {h, c}, 2*512 floats, or NULL: the
+ * state the chain starts from, as ValueNetworkRNN.hidden_cell carries it from call to call,
+ * models.py:133-134); work = icrl_chain_seg_workspace_floats(segments) floats. */
 int64_t icrl_chain_seg_workspace_floats(int segments);
 int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
-                            int segments, int warmup, float* h_emit, float* saved, float* work,
-                            float* seam_err, icrl_stream_t stream);
+                            int segments, int warmup, float* h_emit, float* saved, const float* state_in,
+                            float* work, float* seam_err, icrl_stream_t stream);
 /* saved (may be NULL): the GRU chain's activations {r, z, n, hn, h}, 5*512 floats per position, as
  * icrl_gru_chain_fwd keeps them for icrl_gru_chain_bwd. */
 int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,

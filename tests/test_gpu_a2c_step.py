@@ -595,3 +595,30 @@ def test_reward_pretraining_step_segment_parallel_equals_the_exact_walk():
     for k, g in out["exact"][1].items():
         scale = g.pow(2).mean().sqrt().item() + 1e-12
         assert (out["auto"][1][k] - g).abs().max().item() <= 5e-2 * scale + 1e-9, k
+
+
+def test_lookahead_decoder_joined_value_chains_segment_parallel_equal_the_exact_walk():
+    """The decoder scores the 25 extensions of a step as one value chain, segment-parallel once it is long
+    enough (96 rows here), starting from the state the previous step left.  Same candidates and scores as
+    with the exact walk of the same chain."""
+    models_mod = importlib.import_module("image-captioning-through-rl_amd.models")
+    cfg = dict(n=96, vocab=400, caplen=17, fdim=512, seed=21, level=None)
+    a2c, _ = build_modules(cfg)
+    with torch.no_grad():   # positive logits, as a trained network's top words have: the decoder takes their log
+        a2c.policy_network.linear2vocab.bias += 3.0
+    feats, caps = synthetic.make_minibatch(96, 400, 17, 512, 21)
+    out = {}
+    saved_min = models_mod.SEGMENTED_MIN_POSITIONS
+    try:
+        for mode, threshold in (("segmented", saved_min), ("exact", 1 << 30)):
+            models_mod.SEGMENTED_MIN_POSITIONS = threshold
+            a2c.value_network.valrnn.init_hidden()
+            a2c.value_network.valrnn._seg_warmup = 0
+            out[mode] = trainers.GenerateCaptionsWithActorCriticLookAhead(feats, caps, a2c.policy_network, a2c.value_network)
+            if mode == "segmented":
+                assert a2c.value_network.valrnn._seg_warmup > 0   # the segmented path ran and was accepted
+    finally:
+        models_mod.SEGMENTED_MIN_POSITIONS = saved_min
+    for (tok_s, score_s), (tok_e, score_e) in zip(out["segmented"], out["exact"]):
+        assert torch.equal(tok_s, tok_e)
+        np.testing.assert_allclose(score_s.cpu().numpy(), score_e.cpu().numpy(), rtol=1e-4, atol=1e-4)
