@@ -137,6 +137,25 @@ def _check(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, load().icrl_last_error().decode()))
 
 
+def _chain_shapes(who, n, p0, n_calls, gates, xproj=None, h_emit=None, saved=None, slots=0, d_emit=None, dgates=(),
+                  work=None, segments=None, w_hh=None):
+    """Host-side check that every buffer of a chain call is as large as the kernels' indexing assumes (a
+    kernel that runs past a buffer faults the GPU, it does not raise)."""
+    cols, positions = p0 + n_calls - 1, chain_positions(n, p0, n_calls)
+    def need(t, count, name):
+        if t is not None and not isinstance(t, int):
+            assert t.numel() >= count, "%s: %s has %d elements, the chain needs %d" % (who, name, t.numel(), count)
+    need(xproj, cols * n * gates * 512, "xproj")
+    need(w_hh, gates * 512 * 512, "w_hh")
+    need(h_emit, n_calls * n * 512, "h_emit")
+    need(d_emit, n_calls * n * 512, "d_emit")
+    need(saved, positions * slots * 512, "saved")
+    for i, t in enumerate(dgates):
+        need(t, positions * gates * 512, "dgates[%d]" % i)
+    if work is not None:
+        need(work, chain_seg_workspace_floats(segments), "work")
+
+
 def _f32c(t):
     assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t
@@ -254,6 +273,7 @@ def chain_sync_bytes():
 
 def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, state_in=None, state_out=None):
     """p0 = caption columns seen by the first call; call s covers p0 + s columns."""
+    _chain_shapes("lstm_chain_fwd", n, p0, n_calls, 4, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=6)
     with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_lstm_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, _ptr(_f32c(h_emit)),
                                         _ptr(saved), _ptr(state_in), _ptr(state_out), _ptr(sync_ws), _ptr(status),
@@ -263,6 +283,7 @@ def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, 
 
 def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, state_in=None, state_out=None,
                   saved=None):
+    _chain_shapes("gru_chain_fwd", n, p0, n_calls, 3, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=5)
     with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_gru_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
                                        _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(state_out),
@@ -271,6 +292,8 @@ def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, st
 
 
 def gru_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates_x, dgates_h, sync_ws, status):
+    _chain_shapes("gru_chain_bwd", n, p0, n_calls, 3, w_hh=w_hh, saved=saved, slots=5, d_emit=d_emit,
+                  dgates=(dgates_x, dgates_h))
     _check(load().icrl_gru_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
                                      _ptr(_f32c(dgates_x)), _ptr(_f32c(dgates_h)), _ptr(sync_ws), _ptr(status),
                                      _stream()), "icrl_gru_chain_bwd")
@@ -285,6 +308,7 @@ def vse_loss(s_matrix, beta, row_scratch, loss, d_s=None):
 
 
 def lstm_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates, sync_ws, status):
+    _chain_shapes("lstm_chain_bwd", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit, dgates=(dgates,))
     with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_lstm_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
                                         _ptr(_f32c(dgates)), _ptr(sync_ws), _ptr(status), _stream())
@@ -403,6 +427,8 @@ def chain_seg_workspace_floats(segments):
 
 def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, work, seam_err, state_in=None):
     """state_in: {h, c} (1024 floats) the chain starts from; None = zeros."""
+    _chain_shapes("lstm_chain_fwd_seg", n, p0, n_calls, 4, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=6,
+                  work=work, segments=segments)
     with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_lstm_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, segments, warmup,
                                             _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(_f32c(work)),
@@ -411,6 +437,8 @@ def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, sa
 
 
 def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err, saved=None):
+    _chain_shapes("gru_chain_fwd_seg", n, p0, n_calls, 3, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=5,
+                  work=work, segments=segments)
     with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
         rc = load().icrl_gru_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
                                            segments, warmup, _ptr(_f32c(h_emit)), _ptr(saved), _ptr(_f32c(work)),
@@ -419,6 +447,8 @@ def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emi
 
 
 def gru_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates_x, dgates_h, work, seam_err):
+    _chain_shapes("gru_chain_bwd_seg", n, p0, n_calls, 3, w_hh=w_hh, saved=saved, slots=5, d_emit=d_emit,
+                  dgates=(dgates_x, dgates_h), work=work, segments=segments)
     _check(load().icrl_gru_chain_bwd_seg(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
                                          segments, warmup, _ptr(_f32c(dgates_x)), _ptr(_f32c(dgates_h)),
                                          _ptr(_f32c(work)), _ptr(seam_err), _stream()), "icrl_gru_chain_bwd_seg")
@@ -432,6 +462,10 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
                        saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r, warmup_r=None):
     """Value LSTM chain and reward GRU chain, every step, in one persistent launch (warmup_r: the
     reward chain's own warm-up length; default: the value chain's)."""
+    _chain_shapes("chain_pair_fwd_seg (value)", n, p0_v, n_calls, 4, xproj=xproj_v, w_hh=w_hh_v, h_emit=h_emit_v,
+                  saved=saved_v, slots=6, work=work_v, segments=segments)
+    _chain_shapes("chain_pair_fwd_seg (reward)", n, p0_r, n_calls, 3, xproj=xproj_r, w_hh=w_hh_r, h_emit=h_emit_r,
+                  work=work_r, segments=segments)
     with _Timed("chain_pair_fwd", chain_positions(n, p0_v, n_calls) + chain_positions(n, p0_r, n_calls)):
         rc = load().icrl_chain_pair_fwd_seg(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
                                             _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls,
@@ -445,6 +479,10 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
 def chain_pair_fwd_rows(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, h_emit_v, saved_v, h_emit_r,
                         work_v, work_r, status, persistent=True):
     """Value LSTM and reward GRU with every row its own chain (the reference's classes at batch size 1)."""
+    _chain_shapes("chain_pair_fwd_rows (value)", n, p0_v, n_calls, 4, xproj=xproj_v, w_hh=w_hh_v, h_emit=h_emit_v,
+                  saved=saved_v, slots=6, work=work_v, segments=n)
+    _chain_shapes("chain_pair_fwd_rows (reward)", n, p0_r, n_calls, 3, xproj=xproj_r, w_hh=w_hh_r, h_emit=h_emit_r,
+                  work=work_r, segments=n)
     assert status.dtype == torch.int32
     with _Timed("chain_pair_fwd", chain_positions(1, p0_v, n_calls) + chain_positions(1, p0_r, n_calls)):
         rc = load().icrl_chain_pair_fwd_rows(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
@@ -456,6 +494,8 @@ def chain_pair_fwd_rows(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r,
 
 
 def lstm_chain_bwd_rows(w_hh, saved, d_emit, n, p0, n_calls, dgates, work, status, persistent=True):
+    _chain_shapes("lstm_chain_bwd_rows", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit,
+                  dgates=(dgates,), work=work, segments=n)
     assert status.dtype == torch.int32
     with _Timed("lstm_chain_bwd", chain_positions(1, p0, n_calls)):
         rc = load().icrl_lstm_chain_bwd_rows(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
@@ -465,6 +505,8 @@ def lstm_chain_bwd_rows(w_hh, saved, d_emit, n, p0, n_calls, dgates, work, statu
 
 
 def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False):
+    _chain_shapes("lstm_chain_bwd_seg", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit,
+                  dgates=(dgates,), work=work, segments=segments)
     fn = load().icrl_lstm_chain_bwd_seg_persist if persistent else load().icrl_lstm_chain_bwd_seg
     with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
         rc = fn(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
