@@ -673,17 +673,25 @@ struct ChainArgs {
 __device__ __forceinline__ float4 as_f4(v4u v) { return __builtin_bit_cast(float4, v); }
 __device__ __forceinline__ v4u as_u4(float4 v) { return __builtin_bit_cast(v4u, v); }
 
-// wave 0: lanes 0..15 each poll one producer's flag, lane 16 polls the abort word
-__device__ __forceinline__ void wait_row_group(unsigned* flags16, unsigned epoch, unsigned* abort_w, int lane) {
+// A flag word: step count in the low 24 bits, the producer's XCD in the high 8
+constexpr unsigned EPOCH_MASK = 0x00ffffffu;
+__device__ __forceinline__ unsigned my_xcd() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u; }  // XCC_ID[3:0]
+
+// wave 0: lanes 0..15 each poll one producer's flag, lane 16 polls the abort word.  Returns whether all
+// 16 producers of the row group run on XCD `xcd` (then their plain stores sit in this XCD's L2, where
+// an sc1 load finds them).
+__device__ __forceinline__ bool wait_row_group(unsigned* flags16, unsigned epoch, unsigned* abort_w, int lane,
+                                               unsigned xcd = 0) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        unsigned v = epoch, ab = 0;
+        unsigned v = epoch | (xcd << 24), ab = 0;
         if (lane < 16) v = __hip_atomic_load((gu32*)(flags16 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (lane == 16) ab = __hip_atomic_load((gu32*)abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(v >= epoch) || __any(ab != 0)) return;
+        if (__any(ab != 0)) return false;
+        if (__all((v & EPOCH_MASK) >= epoch)) return __all((v >> 24) == xcd);
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
             if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+            return false;
         }
         __builtin_amdgcn_s_sleep(1);
     }
@@ -923,7 +931,7 @@ struct BwdArgs {
     const float* w_hh; const float* saved; const float* d_emit;
     float* dgx;               // [2][K][4H] exchanged dgates
     float* dc; float* dgv; float* seam_a; float* dh_fin;
-    unsigned* flags;          // [row tiles][16]
+    unsigned* flags;          // [row tiles][32], 16 used
     Geom g;
 };
 
@@ -952,26 +960,42 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     // 84 KB although the stages need 70: two of these workgroups must never share a CU (they would
     // halve the chain's speed for the whole launch), while a GEMM workgroup of another stream still fits
     constexpr int LDS_FLOATS = 21 * 1024;
-    static_assert(LDS_FLOATS >= 2 * PBUF2, "stage buffers");
+    static_assert(LDS_FLOATS >= 2 * PBUF2 && TILE2 >= 32 * PLD, "stage buffers, partial tile inside a wave's stage tile");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     const Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int bx = blockIdx.x % 16, by = blockIdx.x / 16;
+    // Workgroup b is dispatched to XCD b % 8.  With a multiple of 8 row groups, the 16 workgroups of a
+    // row group are given ids of one residue, so that their exchange can stay inside that XCD's L2
+    // (checked at run time through the XCD ids in the flags: `local`).
+    const int groups = gridDim.x / 16;
+    int bx = blockIdx.x % 16, by = blockIdx.x / 16;
+    if (groups % 8 == 0) {
+        const int s = blockIdx.x / 8;
+        bx = s % 16;
+        by = (blockIdx.x % 8) * (groups / 8) + s / 16;
+    }
+    const unsigned xcd = my_xcd();
+    int* local_w = reinterpret_cast<int*>(lds + LDS_FLOATS - 4);
+    bool local = false;
     const int row0 = by * 32, u0 = bx * 32;
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(a.dgx, 0, (int)(2 * (int64_t)g.K * 4 * H * sizeof(float)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.w_hh), 0, (int)((int64_t)4 * H * H * sizeof(float)), 0x00020000);
 
-    // staging map: slot i of a stage belongs to wave-quarter i (gate rows i*512 ...); A: row tid/8, float4 tid%8
-    // of the 32 k; B: k row tid/8, float4 tid%8 of the 32 units
-    const int sr = tid >> 3, sq = tid & 7;
-    const int a_off = (min(row0 + sr, g.K - 1) * 4 * H + 4 * sq) * 4;   // + i*H floats + stage*BK2 floats
-    const int b_off = (sr * H + u0 + 4 * sq) * 4;                       // + (i*H + stage*BK2) * H floats
-    const int a_dst = sr * LDA2 + 4 * sq, b_dst = 32 * LDA2 + sr * 32 + 4 * sq;
-#define A_LOAD(i, stage, base) __builtin_amdgcn_raw_buffer_load_b128(rs, a_off, (base) + ((i) * H + (stage) * BK2) * 4, SC1)
-#define B_LOAD(i, stage) as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, b_off, ((i) * H + (stage) * BK2) * H * 4, 0))
+    // staging map: every wave stages its own tiles (its 512 gate rows are its k range), so the k loop
+    // needs no workgroup barrier: a wave's LDS stores and loads execute in order.  Piece i of a stage:
+    // A row lane/8 + 8i, float4 lane%8 of the 32 k; B k row lane/8 + 8i, float4 lane%8 of the 32 units
+    const int sr = lane >> 3, sq = lane & 7;
+    int a_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = (min(row0 + sr + 8 * i, g.K - 1) * 4 * H + w * H + 4 * sq) * 4;  // + stage*BK2 floats
+    const int b_off = ((w * H + sr) * H + u0 + 4 * sq) * 4;             // + (8i + stage*BK2) * H floats
+    const int a_dst = sr * LDA2 + 4 * sq, b_dst = 32 * LDA2 + sr * 32 + 4 * sq;   // + 8i rows
+#define A_LOAD(i, stage, base) __builtin_amdgcn_raw_buffer_load_b128(rs, a_off[i], (base) + (stage) * BK2 * 4, SC1)
+#define B_LOAD(i, stage) as_f4(__builtin_amdgcn_raw_buffer_load_b128(rw, b_off, (8 * (i) + (stage) * BK2) * H * 4, 0))
+#define WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
     // this thread's epilogue item and its carried dc
     const int rr = tid >> 3, uq = 4 * (tid & 7);
@@ -979,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     const bool have_row = j < g.K;
     float4 dcv = zero4();
     int ps = 0, pt = 0, pi = 0;
-    const float* tile = lds + w * TILE2;
+    float* tile = lds + w * TILE2;
 
     const int steps = g.W + g.Ls;
     for (int mp = 0; mp <= steps; ++mp) {
@@ -1009,8 +1033,12 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
             for (int d = 0; d < PDEPTH; ++d)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ring_b[d][i] = B_LOAD(i, d);
-            if (w == 0) wait_row_group(a.flags + by * 16, (unsigned)mp, abort_w, lane);
+            if (w == 0) {
+                const bool l = wait_row_group(a.flags + by * 32, (unsigned)mp, abort_w, lane, xcd);
+                if (lane == 0) *local_w = l;
+            }
             __syncthreads();
+            local = *local_w != 0;
             const int a_base = (cur ^ 1) * g.K * 4 * H * 4;
 #pragma unroll
             for (int d = 0; d < PDEPTH; ++d)
@@ -1019,8 +1047,8 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
 #define STORE_STAGE2(buf, slot)                                                                     \
     {                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
-            st4(lds + (buf) + i * TILE2 + a_dst, as_f4(ring_a[slot][i]));                           \
-            st4(lds + (buf) + i * TILE2 + b_dst, ring_b[slot][i]);                                  \
+            st4(tile + (buf) + a_dst + 8 * i * LDA2, as_f4(ring_a[slot][i]));                       \
+            st4(tile + (buf) + b_dst + 8 * i * 32, ring_b[slot][i]);                                \
         }                                                                                           \
     }
 #define LOAD_STAGE2(slot, stage)                                                                    \
@@ -1032,32 +1060,48 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     }
             STORE_STAGE2(0, 0)
             if (PDEPTH < NK) LOAD_STAGE2(0, PDEPTH)
-            __syncthreads();
+            WAVE_SYNC()
             FragB2 f0 = load_frag2(tile, 0, l31, hh), f1;
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt) {
                 const int co = (kt & 1) * PBUF2, cn = ((kt + 1) & 1) * PBUF2;
                 f1 = load_frag2(tile + co, 1, l31, hh);
                 mfma8(acc, f0);
-                if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
+                if (kt + 1 < NK) {   // this wave's reads of buffer `cn` were issued before these stores
                     STORE_STAGE2(cn, (kt + 1) % PDEPTH)
                     if (kt + 1 + PDEPTH < NK) LOAD_STAGE2((kt + 1) % PDEPTH, kt + 1 + PDEPTH)
-                    __syncthreads();
+                }
+                // issue order: behind each matrix instruction one LDS read, one LDS write and one global
+                // load, so that the matrix unit never waits for a block of staging instructions
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                if (kt + 1 < NK) {
+                    WAVE_SYNC()
                     f0 = load_frag2(tile + cn, 0, l31, hh);
                 }
                 mfma8(acc, f1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
             }
 #undef STORE_STAGE2
 #undef LOAD_STAGE2
-            __syncthreads();  // every wave is done reading before the partial tiles overlay the stage buffers
+            WAVE_SYNC()   // the partial tile below overlays this wave's own stage buffer only
         }
         float* P = lds;
-        acc_to_lds(acc, P + w * 32 * PLD, l31, hh);
+        acc_to_lds(acc, tile, l31, hh);
         __syncthreads();
 
         if (have_row) {
             const float* pr = P + rr * PLD + uq;
-            float4 dh = add4(add4(ldp4(pr), ldp4(pr + 32 * PLD)), add4(ldp4(pr + 64 * PLD), ldp4(pr + 96 * PLD)));
+            float4 dh = add4(add4(ldp4(pr), ldp4(pr + TILE2)), add4(ldp4(pr + 2 * TILE2), ldp4(pr + 3 * TILE2)));
             if (final) {
                 st4(a.dh_fin + (int64_t)j * H + u, dh);
                 st4(a.dc + (int64_t)j * H + u, dcv);
@@ -1078,18 +1122,29 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
                 dcv = dcn;
                 // the exchanged copy of this step's dgates: write-through, 16 bytes per lane
                 const int o = (j * 4 * H + u) * 4, sb = cur * g.K * 4 * H * 4;
-                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_i), rs, o, sb, SC1);
-                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_f), rs, o + H * 4, sb, SC1);
-                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_g), rs, o + 2 * H * 4, sb, SC1);
-                __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_o), rs, o + 3 * H * 4, sb, SC1);
+                if (local) {   // every reader shares this XCD's L2: no write-through needed
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_i), rs, o, sb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_f), rs, o + H * 4, sb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_g), rs, o + 2 * H * 4, sb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_o), rs, o + 3 * H * 4, sb, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_i), rs, o, sb, SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_f), rs, o + H * 4, sb, SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_g), rs, o + 2 * H * 4, sb, SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(d_o), rs, o + 3 * H * 4, sb, SC1);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
         __syncthreads();                                    // ... before ONE lane signals for all of them
-        if (tid == 0 && !final)
-            __hip_atomic_store((gu32*)(a.flags + by * 16 + bx), (unsigned)(mp + 1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !final) {
+            const unsigned word = (unsigned)(mp + 1) | (xcd << 24);
+            gu32* fp = (gu32*)(a.flags + by * 32 + bx);
+            if (local) __hip_atomic_store(fp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(fp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+#undef WAVE_SYNC
 #undef A_LOAD
 #undef B_LOAD
 }
@@ -1187,11 +1242,12 @@ int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out) {
     const int64_t kh = (int64_t)K * H;
     const int ny = (K + 31) / 32;
     unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
-    const size_t word_bytes = ((size_t)(ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    // a 128-byte line of flags per row group: a line is then written from one XCD only when the group is XCD-local
+    const size_t word_bytes = ((size_t)(ny * 32 + 4) * sizeof(unsigned) + 255) / 256 * 256;
     ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
     ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
     a.dgx = work; a.dc = work + 8 * kh; a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
-    *abort_out = words + ny * 16;
+    *abort_out = words + ny * 32;
     hipLaunchKernelGGL(seg_bwd_persist, dim3(16 * ny), dim3(256), 0, st, a, *abort_out);
     return ICRL_OK;
 }

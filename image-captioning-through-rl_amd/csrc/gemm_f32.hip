@@ -205,15 +205,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     tile_store<BN, B_KM>(lds + A_TILE, rb, tid);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
-        const float* lb = la + A_TILE;
-        if (kt + 1 < nk) {
-            if (fast_a && kt + 1 < nk_full) tile_load_fast<BM>(ra, pa, (kt + 1) * step_a);
-            else tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, tid);
-            if (fast_b && kt + 1 < nk_full) tile_load_fast<BN>(rb, pb, (kt + 1) * step_b);
-            else tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, tid);
-        }
+    // one k stage of matrix instructions from the LDS buffers la / lb
+    auto stage_mfma = [&](const float* la, const float* lb) {
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
             float av[TM][8], bv[TN][8];
@@ -231,6 +224,60 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
         }
+    };
+
+    int kt = 0;
+    // Interior tiles: every stage but the last few is whole and aligned; their loop carries no bounds
+    // logic at all (the general loop below, even when its branches are never taken, costs several
+    // hundred predicated instructions per stage).
+    if (fast_a && fast_b) {
+        // one interior stage: compute from buffer `cur` (a compile-time 0 / 1 in the unrolled pair below, so
+        // that every LDS address is a constant offset from a per-thread base), stage kt + 1 into the other
+        auto interior = [&](const float* la, float* wa) {
+            tile_load_fast<BM>(ra, pa, (kt + 1) * step_a);
+            tile_load_fast<BN>(rb, pb, (kt + 1) * step_b);
+            stage_mfma(la, la + A_TILE);
+            tile_store<BM, A_KM>(wa, ra, tid);
+            tile_store<BN, B_KM>(wa + A_TILE, rb, tid);
+            // issue order of the stage: the next stage's global loads first (their latency runs under the
+            // whole stage), LDS fragment reads spread between the matrix instructions, the LDS stores of the
+            // loaded tiles between the last ones
+            constexpr int NM = TM * TN * 16, NL = (BM + BN) / 32;
+            __builtin_amdgcn_sched_group_barrier(0x020, NL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < NM - NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __syncthreads();
+        };
+        float* const buf1 = lds + A_TILE + B_TILE;
+        // (the pair costs a little set-up: only worth it for long k loops)
+        for (; nk_full >= 64 && kt + 2 < nk_full; kt += 2) {   // kt is even here
+            interior(lds, buf1);
+            ++kt;
+            interior(buf1, lds);
+            --kt;
+        }
+        for (; kt + 1 < nk_full; ++kt)
+            interior(lds + (kt & 1) * (A_TILE + B_TILE), lds + ((kt + 1) & 1) * (A_TILE + B_TILE));
+    }
+    for (; kt < nk; ++kt) {
+        const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
+        const float* lb = la + A_TILE;
+        if (kt + 1 < nk) {
+            if (fast_a && kt + 1 < nk_full) tile_load_fast<BM>(ra, pa, (kt + 1) * step_a);
+            else tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + 1) * BK, kend, g.a_vec, tid);
+            if (fast_b && kt + 1 < nk_full) tile_load_fast<BN>(rb, pb, (kt + 1) * step_b);
+            else tile_load<BN, B_KM>(rb, g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + 1) * BK, kend, g.b_vec, tid);
+        }
+        stage_mfma(la, lb);
         if (kt + 1 < nk) {
             float* wa = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
             tile_store<BM, A_KM>(wa, ra, tid);
