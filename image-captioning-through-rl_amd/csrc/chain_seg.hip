@@ -794,6 +794,13 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                 for (int i = 0; i < 2; ++i)
                     ring_a[d][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_off[i], a_base + d * BK * 4, SC1);
 
+#define ISSUE_INTERLEAVED(n)                                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                  \
+    }
 #define STORE_STAGE(buf, slot)                                                                              \
     {                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                       \
@@ -824,6 +831,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                     }
                     mfma8g(acc[0], f, 0);
                     mfma8g(acc[1], f, 1);
+                    ISSUE_INTERLEAVED(24)   // between two barriers: behind each matrix instruction one LDS read, one LDS write, one global load
                     if (kt + 1 < NK) {
                         __syncthreads();
                         fn = load_frag_k(a_row + cn, b_row0 + cn, 32 * BK, o0, o1);
@@ -846,6 +854,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                     mfma8(acc[0], f1);
                     f1 = load_frag_swz(a_row + co, b_row + co, fo, 3);
                     mfma8(acc[0], f0);
+                    ISSUE_INTERLEAVED(32)
                     if (kt + 1 < NK) {
                         __syncthreads();
                         f0 = load_frag_swz(a_row + cn, b_row + cn, fo, 0);
@@ -853,6 +862,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                     mfma8(acc[0], f1);
                 }
             }
+#undef ISSUE_INTERLEAVED
 #undef STORE_STAGE
 #undef LOAD_STAGE
             __syncthreads();  // every wave is done reading before the gate tiles overlay the stage buffers
