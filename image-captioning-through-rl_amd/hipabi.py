@@ -369,8 +369,8 @@ def sum_slabs(slabs, out, accumulate=False):
 def plan_gemm(m, n, k, out_contiguous=True, shared=False):
     """(tile, splits) for an [m,n,k] product, from measurements on MI355X (tools/gemm_sweep.py).
     shared: the launch will run beside a persistent chain kernel that holds half of every CU's LDS and
-    registers; only the smaller tiles co-reside with it in useful numbers, so the 128x128 choice below,
-    faster on an empty device, is not made.
+    registers; two 64x64-tile workgroups still fit beside it on a CU, one of the larger tiles at most, so
+    the 128x128 choice below, faster on an empty device, is not made (measured on the whole minibatch).
     tile codes: 1 = 128x128, 2 = 128x64, 3 = 64x64.  Short k loops: 64x64 tiles.  Small outputs: 64x64
     tiles, k split so that about a thousand workgroups exist.  Otherwise 128x128 tiles with the split
     that best fills the 256 CUs: a CU's last, partly filled turn costs as much as a full one, few
@@ -382,8 +382,7 @@ def plan_gemm(m, n, k, out_contiguous=True, shared=False):
         return (3 if t64 <= 512 else 2), 1
     t128 = ((m + 127) // 128) * ((n + 127) // 128)
     if shared and t64 > 512:
-        t2 = ((m + 127) // 128) * ((n + 63) // 64)
-        return 2, (2 if (t2 < 1024 and k >= 4096) else 1)
+        return 3, (2 if k >= 2048 else 1)
     if t128 < 32 or shared:
         want = (2048 if k >= 32768 else 1024) // t64
         splits = max(1, min(k // 512, want, 16))
