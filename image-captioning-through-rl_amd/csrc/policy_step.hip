@@ -226,13 +226,21 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_pipelined(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float4 ring[DEPTH][PER];
-    // stage kt of the k loop: word-vector columns first (gathered rows are copied out on the way), then h
+    // stage kt of the k loop: word-vector columns first, then h.  The gathered rows are copied out when
+    // their stage moves from the ring to LDS (by then the load has landed: a copy right behind the load
+    // would wait for it and drain the ring).
+#define STAGE_TO_LDS(buf, slot, kt)                                                                 \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                           \
+            st4(lds + (buf) + dst[i], ring[slot][i]);                                               \
+            if ((kt) < NK1 && copy_x[i]) st4(copy_x[i] + (kt) * BK, ring[slot][i]);                 \
+        }                                                                                           \
+    }
 #define STAGE_LOAD(slot, kt)                                                                        \
     {                                                                                               \
         _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                           \
             if ((kt) < NK1) {                                                                       \
                 ring[slot][i] = ld4(src_x[i] + (kt) * BK);                                          \
-                if (copy_x[i]) st4(copy_x[i] + (kt) * BK, ring[slot][i]);                           \
             } else {                                                                                \
                 ring[slot][i] = ld4(src_h[i] + ((kt) - NK1) * BK);                                  \
             }                                                                                       \
@@ -240,8 +248,7 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_pipelined(const float* __
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) STAGE_LOAD(d, d)
-#pragma unroll
-    for (int i = 0; i < PER; ++i) st4(lds + dst[i], ring[0][i]);
+    STAGE_TO_LDS(0, 0, 0)
     STAGE_LOAD(0, DEPTH)
     __syncthreads();
     const float* a_row = lds + l31 * LDT;
@@ -253,8 +260,7 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_pipelined(const float* __
         f1 = load_frag(a_row + co, b_row + co, 1, hh);
         mfma8(acc, f0);
         if (kt + 1 < NK) {   // nobody reads buffer `cn` any more: the previous stage's barrier came after its last read
-#pragma unroll
-            for (int i = 0; i < PER; ++i) st4(lds + cn + dst[i], ring[(kt + 1) % DEPTH][i]);
+            STAGE_TO_LDS(cn, (kt + 1) % DEPTH, kt + 1)
             if (kt + 1 + DEPTH < NK) STAGE_LOAD((kt + 1) % DEPTH, kt + 1 + DEPTH)
         }
         f0 = load_frag(a_row + co, b_row + co, 2, hh);
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(NT) void policy_lstm_step_pipelined(const float* __
         mfma8(acc, f1);
     }
 #undef STAGE_LOAD
+#undef STAGE_TO_LDS
     __syncthreads();   // every wave is done reading before the gate tiles overlay the stage buffers
     float* P = lds + q * 32 * PLD;
 #pragma unroll
