@@ -45,18 +45,23 @@ class A2CStepResult:
     """Device tensors of one minibatch.  tokens [N, p0+S] int64; log_probs, values,
     rewards [N, S] float32; scalars[0..4] = loss, actor, critic, mean reward, mean adv."""
 
-    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status, chain_plan=None, reward_plan=None):
+    def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status, chain_plan=None, reward_plan=None,
+                 status_host=None):
         self.tokens, self.log_probs, self.values, self.rewards = tokens, log_probs, values, rewards
         self.scalars, self.entropy, self.status = scalars, entropy, status
+        # the status words as read back together with the backward seam check (after every chain kernel of
+        # the minibatch had finished), when the step made that read; check() then needs no second round trip
+        self.status_host = status_host
         # (value chain forward, value chain backward), each ("exact",), ("segmented", segments, warmup) or ("rows",)
         self.chain_plan = chain_plan
         self.reward_plan = reward_plan  # the same for the reward chain (forward only)
 
     def check(self):
-        """Synchronises; raises if a chain kernel gave up waiting for a peer workgroup."""
-        st = self.status.cpu()
-        if int(st.abs().sum()) != 0:
-            raise RuntimeError("a persistent chain kernel timed out (status %s)" % st.tolist())
+        """Raises if a chain kernel gave up waiting for a peer workgroup.  Synchronises unless the step has
+        already read the status words back (it does whenever it checks a backward seam)."""
+        st = self.status_host if self.status_host is not None else self.status.cpu().tolist()
+        if any(st):
+            raise RuntimeError("a persistent chain kernel timed out (status %s)" % list(st))
         return self
 
 
@@ -215,9 +220,10 @@ class A2CEngine:
 
         ws = dict(tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev), tv=tv,
                   scalars=torch.zeros(8, dtype=torch.float32, device=dev),
-                  status=torch.zeros(4, dtype=torch.int32, device=dev),
-                  seam=torch.zeros(6, dtype=torch.float32, device=dev),
-                  seam_host=torch.zeros(4, dtype=torch.float32).pin_memory())
+                  ctl=torch.zeros(12, dtype=torch.float32, device=dev),   # seam errors [0:6], status words [8:12]
+                  seam_host=torch.zeros(4, dtype=torch.float32).pin_memory(),
+                  ctl_host=torch.zeros(8, dtype=torch.float32).pin_memory())
+        ws["seam"], ws["status"] = ws["ctl"][0:6], ws["ctl"][8:12].view(torch.int32)
         widths = [H]
         if self.P is not None:
             v, e = self.vocab, self.E
@@ -321,7 +327,10 @@ class A2CEngine:
         t_steps = p0 - 1 + s
         tokT = ws["tokT"]
         Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
-        hip.gemm(features, P["cnn2linear.weight"], Hb[0], bias=P["cnn2linear.bias"])
+        # h0 = cnn2linear(features): a 64-tile output with a long k, first on the step's critical path; k is
+        # split over workgroups (partial slabs summed on top of the bias)
+        Hb[0].copy_(P["cnn2linear.bias"].expand_as(Hb[0]))
+        hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True)
         fused_step = self.E % 64 == 0
         for k in range(t_steps):
             if fused_step:  # gather + both gate products + cell in one launch
@@ -546,9 +555,21 @@ class A2CEngine:
         main = torch.cuda.current_stream()
 
         self._mark("start")
+        side = self._side_stream() if self.concurrent else main
+        # the two products of the image features that the heads need after the chains (visual embedding,
+        # feature half of the value head's first layer) depend on nothing the step computes: they run on
+        # the side stream beside the rollout, whose small launches leave most of the device idle
+        ev_start = torch.cuda.Event()
+        ev_start.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_start)
+            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+            hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
+            ev_feat = torch.cuda.Event()
+            ev_feat.record(side)
         self._rollout(ws, features, n, p0, s, uniforms, mode)
         self._mark("rollout_done")
-        side = self._side_stream() if self.concurrent else main
+        main.wait_event(ev_feat)
         plans = self._plans(ws)
         last = len(plans) - 1
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
@@ -589,8 +610,18 @@ class A2CEngine:
         if with_bwd and self.on_policy_grads is not None:
             # the forward pass stands, so the policy gradients being computed now are final
             self.on_policy_grads(self._ev_policy)
+        # the tensors handed back are final now; their copies queue behind the backward pass
+        out = (tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
+               ws["rewards"].view(s, n).t().contiguous())
+        status_host = None
         while with_bwd and pb[0] == "segmented":
-            seam_b = ws["seam"][4:6].tolist()  # host sync; the caller synchronises per step anyway
+            # one read-back for the backward seam and the status words (the step's one host sync)
+            ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
+            ev_ctl = torch.cuda.Event()
+            ev_ctl.record(main)
+            ev_ctl.synchronize()
+            seam_b = ws["ctl_host"][0:2].tolist()
+            status_host = ws["ctl_host"][4:8].view(torch.int32).tolist()
             self.last_seam[4:6] = seam_b
             checks_b = [(seam_b[0] / seam_b[1] if seam_b[1] > 0 else 0.0, self.SEAM_TOL_BWD)]
             if all(e <= t for e, t in checks_b):
@@ -602,10 +633,8 @@ class A2CEngine:
             pb = plans[bi]
             self._value_chain_backward(ws, n, p0, s, main, side, pb, None)
             self._mark("backward_done")
-        return A2CStepResult(tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
-                             ws["rewards"].view(s, n).t().contiguous(), ws["scalars"],
-                             ws["entropy"] if self.want_entropy else None, ws["status"],
-                             (pv, pb), pr)
+        return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
+                             (pv, pb), pr, status_host)
 
     def _chains_forward_loss(self, ws, features, n, p0, s, backward, main, side, plan, plan_r):
         """The two forward chains, the heads and the loss.  plan / plan_r: how the value / reward chain
@@ -626,7 +655,6 @@ class A2CEngine:
             hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["XPr"],
                      a_rows=tok_flat[:l_cols * n], bias=R["rewrnn.gru.bias_ih_l0"])
             if pair:
-                hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
                 ev_xpr = torch.cuda.Event()
                 ev_xpr.record(side)
             elif seg_r:
@@ -636,7 +664,7 @@ class A2CEngine:
                 hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                   ws["hr"], ws["sync_r"], ws["status"][1:2])
             if not pair:
-                self._reward_head(ws, features, n, s, side)
+                self._reward_head(ws, features, n, s, side, visual_done=True)
                 ev_rew = torch.cuda.Event()
                 ev_rew.record(side)
         hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
@@ -671,7 +699,6 @@ class A2CEngine:
             hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, ws["hv"],
                                ws["saved"] if backward else None, ws["sync_v"], ws["status"][0:1])
         w1 = V["linear1.weight"]
-        hip.gemm(features, w1[:, :self.F], ws["U"], bias=V["linear1.bias"])
         hip.gemm(ws["hv"].view(s * n, H), w1[:, self.F:], ws["Y"])
         hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], s * n, n, ws["values"])
         self._mark("value_fwd_done")
