@@ -149,3 +149,17 @@ def test_warmup_ladder_moves_up_before_failing_and_probes_down_with_a_cooldown()
     assert lad.first == 1
     lad.accepted(1, [(0.05 * tol, tol)], 2)
     assert lad.first == 0 and lad.probing
+
+
+def test_step_result_check_uses_the_status_words_read_back_with_the_seam():
+    engine = importlib.import_module("image-captioning-through-rl_amd.engine")
+    dev_status = torch.zeros(4, dtype=torch.int32)
+    ok = engine.A2CStepResult(None, None, None, None, None, None, dev_status, status_host=[0, 0, 0, 0])
+    assert ok.check() is ok
+    bad = engine.A2CStepResult(None, None, None, None, None, None, dev_status, status_host=[0, 0, 1, 0])
+    with pytest.raises(RuntimeError, match="timed out"):
+        bad.check()
+    # without a host copy the device words are read
+    dev_status[1] = 1
+    with pytest.raises(RuntimeError, match="timed out"):
+        engine.A2CStepResult(None, None, None, None, None, None, dev_status).check()
