@@ -570,6 +570,20 @@ __global__ __launch_bounds__(256) void seg_gru_bwd_step(const float* __restrict_
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { st4(nxt + adst[i], sa[i]); st4(nxt + bdst[i], sb[i]); }
             }
+            // issue order of the stage: the next stage's global loads first, LDS reads between the matrix
+            // instructions, the LDS stores of the loaded stage between the last ones
+            __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
             __syncthreads();
         }
     }
