@@ -84,8 +84,10 @@ class PolicyNetwork(nn.Module):
         self.linear2vocab = nn.Linear(hidden_dim, vocab_size)
 
     @torch.no_grad()
-    def forward(self, features, captions):
-        """features [1,N,F], captions [N,p] -> logits [N,p,V] (models.py:71-84)."""
+    def forward(self, features, captions, last_only=False):
+        """features [1,N,F], captions [N,p] -> logits [N,p,V] (models.py:71-84).  last_only (not in the
+        reference): project only the newest position, logits [N,1,V] - what a caller that slices
+        [:, -1, :] needs, without the p - 1 other vocabulary products."""
         w = self.cnn2linear.weight
         feats = _dev_f32(features, w.device).reshape(-1, w.shape[1])
         caps = torch.as_tensor(captions, device=w.device).long()
@@ -93,15 +95,20 @@ class PolicyNetwork(nn.Module):
         tok_t = caps.t().contiguous()
         hs = torch.empty(p + 1, n, H, device=w.device)
         c_prev, c_next = torch.zeros(n, H, device=w.device), torch.empty(n, H, device=w.device)
-        gates = torch.empty(n, 4 * H, device=w.device)
+        # the input side of every position in one product (it does not depend on the state) ...
+        gates = torch.empty(p, n, 4 * H, device=w.device)
+        hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, gates.view(p * n, 4 * H), a_rows=tok_t.view(-1),
+                 bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
         hip.gemm(feats, w, hs[0], bias=self.cnn2linear.bias)
-        for t in range(p):
-            hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, gates, a_rows=tok_t[t],
-                     bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
-            hip.gemm(hs[t], self.lstm.weight_hh_l0, gates, accumulate=True)
-            hip.lstm_cell_fwd(gates, c_prev, c_next, hs[t + 1])
+        for t in range(p):   # ... then per position the recurrent product on top of it and the cell
+            hip.gemm(hs[t], self.lstm.weight_hh_l0, gates[t], accumulate=True)
+            hip.lstm_cell_fwd(gates[t], c_prev, c_next, hs[t + 1])
             c_prev, c_next = c_next, c_prev
         vocab = self.linear2vocab.weight.shape[0]
+        if last_only:
+            logits = torch.empty(n, vocab, device=w.device)
+            hip.gemm(hs[p], self.linear2vocab.weight, logits, bias=self.linear2vocab.bias)
+            return logits.view(n, 1, vocab)
         logits = torch.empty(p * n, vocab, device=w.device)
         hip.gemm(hs[1:].view(p * n, H), self.linear2vocab.weight, logits, bias=self.linear2vocab.bias)
         return logits.view(p, n, vocab).permute(1, 0, 2)

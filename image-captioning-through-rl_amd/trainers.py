@@ -97,8 +97,12 @@ def GenerateCaptionsWithActorCriticLookAhead(features, captions, policy_network,
         # sees the first of them; it then scores them in the reference's order (candidate by candidate,
         # word by word, its state running through), as one chain
         extensions = []
-        for cand, cand_score in candidates:
-            logits = policy_network(feats.unsqueeze(0), cand)[:, -1, :].contiguous()
+        # ... and row-wise, so the kept candidates go through it stacked along the batch dimension
+        n_rows, k_c = gen_caps.shape[0], len(candidates)
+        stacked = policy_network(feats.repeat(k_c, 1).unsqueeze(0), torch.cat([c for c, _ in candidates], dim=0),
+                                 last_only=True)[:, -1, :]
+        for j, (cand, cand_score) in enumerate(candidates):
+            logits = stacked[j * n_rows:(j + 1) * n_rows].contiguous()
             top_vals, top_words = hip.topk_rows(logits, beamSize)
             for i in range(beamSize):
                 extensions.append((torch.cat((cand, top_words[:, i:i + 1]), dim=1), cand_score, top_vals[:, i:i + 1]))
