@@ -111,7 +111,7 @@ def GenerateCaptionsWithActorCriticLookAhead(features, captions, policy_network,
         for (cap, cand_score, top_val), value in zip(extensions, values):
             score_delta = 0.6 * value + 0.4 * torch.log(top_val)
             next_candidates.append((cap, cand_score - score_delta))
-        means = [float(c[1].mean()) for c in next_candidates]       # one read-back per candidate
+        means = torch.stack([c[1].mean() for c in next_candidates]).tolist()   # one read-back per step
         order = sorted(range(len(next_candidates)), key=lambda j: means[j])
         candidates = [next_candidates[j] for j in order[:beamSize]]
     if most_likely:
