@@ -439,6 +439,12 @@ def test_module_forwards_carry_hidden_state_like_the_reference():
     _, want_l, _ = orc.policy_rollout(Pp, feats, caps[:, :1], 4, mode="forced", forced=caps[:, 1:5])
     assert tuple(logits.shape) == (6, 4, 80)
     np.testing.assert_allclose(logits.permute(1, 0, 2).cpu().numpy(), want_l.numpy(), rtol=RTOL, atol=ATOL)
+    # last_only: the newest position alone, bit-equal to the slice of the full result, also for stacked batches
+    last = a2c.policy_network(torch.from_numpy(feats).cuda().unsqueeze(0), toks[:, :4].cuda(), last_only=True)
+    assert tuple(last.shape) == (6, 1, 80) and torch.equal(last[:, 0], logits[:, -1])
+    both = a2c.policy_network(torch.from_numpy(feats).cuda().repeat(2, 1).unsqueeze(0),
+                              torch.cat((toks[:, :4], toks[:, 1:5]), dim=0).cuda(), last_only=True)
+    assert torch.equal(both[:6, 0], logits[:, -1])
     values, probs = a2c(torch.from_numpy(feats).cuda(), toks[:, :3].cuda())
     assert tuple(values.shape) == (6, 1) and tuple(probs.shape) == (6, 1, 80)
 
