@@ -678,6 +678,7 @@ constexpr unsigned long long SPIN_LIMIT = 2000000ull;  // 20 ms of the 100 MHz w
 
 struct ChainArgs {
     const float* xproj; const float* w_hh; const float* b_hh;
+    const float* state_in;    // {h, c} the chain starts from, or null (LSTM chain only)
     float* hb;                // [2][K][H] exchanged state
     float* saved; float* h_emit; float* seam_a; float* seam_b;
     unsigned* flags;          // [row tiles][16]
@@ -894,6 +895,10 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
             float4 h = zero4();
             if (st == 1) {
                 state = zero4();
+                if (G == 4 && a.state_in != nullptr && pos == -1) {   // the step before the chain's first position
+                    h = ld4(a.state_in + u);
+                    state = ld4(a.state_in + H + u);
+                }
             } else {
                 const float* pr = P + rr * PLD + uq;
                 if (G == 4) {
@@ -932,10 +937,13 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
 
 #undef W_LOAD
 
-__global__ __launch_bounds__(256, 2) void seg_fwd_pair_persist(ChainArgs v, ChainArgs r, unsigned* abort_w, int per_chain) {
+// only: 0 = both chains (2 * per_chain workgroups), 1 = the LSTM chain alone, 2 = the GRU chain alone
+// (per_chain workgroups)
+__global__ __launch_bounds__(256, 2) void seg_fwd_pair_persist(ChainArgs v, ChainArgs r, unsigned* abort_w, int per_chain,
+                                                               int only) {
     __shared__ __attribute__((aligned(16))) float lds[2 * PBUF];
     const int id = blockIdx.x % per_chain;
-    if ((int)blockIdx.x < per_chain) persist_chain<4>(v, id % 16, id / 16, abort_w, lds);
+    if (only == 1 || (only == 0 && (int)blockIdx.x < per_chain)) persist_chain<4>(v, id % 16, id / 16, abort_w, lds);
     else persist_chain<3>(r, id % 16, id / 16, abort_w, lds);
 }
 
@@ -1257,7 +1265,28 @@ int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipSt
     r.hb = work_r; r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 16;
     *abort_out = words + 2 * ny * 16;
     const int per_chain = (H / 32) * ny;
-    hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, *abort_out, per_chain);
+    hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, *abort_out, per_chain, 0);
+    return ICRL_OK;
+}
+
+// one forward chain alone in the persistent launch (gates = 4: LSTM, 3: GRU); same workspace layout as
+// the per-step schedules above
+int solo_persist(ChainArgs& a, int gates, float* work, hipStream_t st, unsigned** abort_out) {
+    const int K = a.g.K;
+    const int64_t kh = (int64_t)K * H;
+    const int ny = (K + 31) / 32;
+    unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
+    const size_t word_bytes = ((size_t)(ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
+    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+    ICRL_HIP(hipMemsetAsync(work, 0, sizeof(float) * 2 * kh, st));
+    a.hb = work; a.flags = words;
+    a.seam_a = work + (gates == 4 ? 4 : 2) * kh;
+    a.seam_b = work + (gates == 4 ? 6 : 3) * kh;
+    *abort_out = words + ny * 16;
+    const int per_chain = (H / 32) * ny;
+    hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(per_chain), dim3(256), 0, st, a, a, *abort_out, per_chain,
+                       gates == 4 ? 1 : 2);
     return ICRL_OK;
 }
 
@@ -1390,8 +1419,8 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     hipStream_t st = icrl::as_stream(stream);
     ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
     ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
-    v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v;
-    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = nullptr; r.h_emit = h_emit_r;
+    v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v; v.state_in = nullptr;
+    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = nullptr; r.h_emit = h_emit_r; r.state_in = nullptr;
     unsigned* abort_w = nullptr;
     if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(v.g.K * 2 * H)), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
@@ -1399,6 +1428,53 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(r.g.K * H)), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
                        seam_err_r);
     hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err_v, seam_err_r);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+                                               int segments, int warmup, float* h_emit, float* saved,
+                                               const float* state_in, float* work, float* seam_err,
+                                               icrl_stream_t stream) {
+    ChainArgs a;
+    if (int rc = make_geom("icrl_lstm_chain_fwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
+    ICRL_REQUIRE(xproj && w_hh && h_emit && work && seam_err, "icrl_lstm_chain_fwd_seg_persist: null pointer");
+    ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(h_emit) && aligned16(saved) && aligned16(work) &&
+                 aligned16(state_in), "icrl_lstm_chain_fwd_seg_persist: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(warmup >= 1 || !state_in, "icrl_lstm_chain_fwd_seg_persist: a start state needs a warm-up of at least 1");
+    ICRL_REQUIRE(icrl_chain_pair_supported(segments),
+                 "icrl_lstm_chain_fwd_seg_persist: %d segments need more workgroups than the device has CUs; its "
+                 "workgroups wait for each other and must all be resident", segments);
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
+    a.xproj = xproj; a.w_hh = w_hh; a.b_hh = nullptr; a.saved = saved; a.h_emit = h_emit; a.state_in = state_in;
+    unsigned* abort_w = nullptr;
+    if (int rc = solo_persist(a, 4, work, st, &abort_w)) return rc;
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.seam_b, a.g,
+                       2 * H, seam_err);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err, seam_err);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
+                                              int n_calls, int segments, int warmup, float* h_emit, float* work,
+                                              float* seam_err, icrl_stream_t stream) {
+    ChainArgs a;
+    if (int rc = make_geom("icrl_gru_chain_fwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
+    ICRL_REQUIRE(xproj && w_hh && b_hh && h_emit && work && seam_err, "icrl_gru_chain_fwd_seg_persist: null pointer");
+    ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(b_hh) && aligned16(h_emit) && aligned16(work),
+                 "icrl_gru_chain_fwd_seg_persist: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(icrl_chain_pair_supported(segments),
+                 "icrl_gru_chain_fwd_seg_persist: %d segments need more workgroups than the device has CUs; its "
+                 "workgroups wait for each other and must all be resident", segments);
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
+    a.xproj = xproj; a.w_hh = w_hh; a.b_hh = b_hh; a.saved = nullptr; a.h_emit = h_emit; a.state_in = nullptr;
+    unsigned* abort_w = nullptr;
+    if (int rc = solo_persist(a, 3, work, st, &abort_w)) return rc;
+    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(a.g.K * H)), dim3(256), 0, st, a.seam_a, a.seam_b, a.g, H, seam_err);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err, seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

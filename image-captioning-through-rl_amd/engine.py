@@ -393,7 +393,8 @@ class A2CEngine:
             if redo_forward:
                 if pv[0] == "segmented":
                     hip.lstm_chain_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, 1, pv[1], pv[2], ws["hv"],
-                                           ws["saved"], ws["work_v"], ws["seam"][0:2])
+                                           ws["saved"], ws["work_v"], ws["seam"][0:2],
+                                           persistent=self.persistent and hip.chain_pair_supported(pv[1]))
                 else:
                     hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, 1, ws["hv"], ws["saved"],
                                        ws["sync_v"], ws["status"][0:1])

@@ -204,7 +204,8 @@ class ValueNetworkRNN(nn.Module):
                 self._seg_err = torch.zeros(2, device=dev)
             for warmup in (w for w in SEGMENTED_WARMUPS if w >= self._seg_warmup):
                 hip.lstm_chain_fwd_seg(xproj, self.lstm.weight_hh_l0, n, calls * p, 1, segments, warmup, h_emit, saved,
-                                       self._seg_work, self._seg_err, state_in=state)
+                                       self._seg_work, self._seg_err, state_in=state,
+                                       persistent=hip.chain_pair_supported(segments))
                 if self._seg_err[0].item() <= SEGMENTED_SEAM_TOL:
                     self._seg_warmup, done = warmup, True
                     break
@@ -356,7 +357,7 @@ class RewardNetworkRNN(nn.Module):
             self._seg_err = torch.zeros(2, device=dev)
         for warmup in (w for w in SEGMENTED_WARMUPS if w >= self._seg_warmup):
             hip.gru_chain_fwd_seg(xproj, self.gru.weight_hh_l0, self.gru.bias_hh_l0, n, p, 1, segments, warmup, h_emit,
-                                  self._seg_work, self._seg_err)
+                                  self._seg_work, self._seg_err, persistent=hip.chain_pair_supported(segments))
             if self._seg_err[0].item() <= SEGMENTED_SEAM_TOL:
                 self._seg_warmup = warmup
                 return True

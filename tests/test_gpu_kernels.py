@@ -359,6 +359,25 @@ def test_persistent_chains_equal_the_per_step_launches(n, p0, calls, segs, warm)
         torch.cuda.synchronize()
         assert (err_v[0].item(), err_r[0].item()) == ref_err
         assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
+    # each forward chain alone in the persistent launch, the LSTM one also from a given start state
+    state = dev(rnd(rs, 2 * H, scale=0.3))
+    h_i, saved_i = torch.zeros_like(h_s), torch.zeros_like(saved_s)
+    hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_i, saved_i, work_v, err_v, state_in=state)
+    torch.cuda.synchronize()
+    err_i = err_v[0].item()
+    assert not torch.equal(saved_i[:4], saved_s[:4])   # the first positions feel the start state
+    for _ in range(2):
+        h_p, saved_p, g_p = torch.zeros_like(h_s), torch.zeros_like(saved_s), torch.zeros_like(g_s)
+        hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_p, saved_p, work_v, err_v, persistent=True)
+        hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm_r, g_p, work_r, err_r, persistent=True)
+        torch.cuda.synchronize()
+        assert (err_v[0].item(), err_r[0].item()) == ref_err
+        assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
+        hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_p, saved_p, work_v, err_v, state_in=state,
+                               persistent=True)
+        torch.cuda.synchronize()
+        assert err_v[0].item() == err_i
+        assert torch.equal(h_p, h_i) and torch.equal(saved_p, saved_i)
     # the backward chain: persistent launch against the per-step launches
     d_emit = dev(rnd(rs, calls, n, H, scale=0.01))
     dg_s = torch.zeros(pos_v, 4 * H, device="cuda")
