@@ -918,6 +918,12 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                     const float4 hn = add4(sum_partials(pr + 64 * PLD), bias[G == 3 ? 2 : 0]);
                     GRU_CELL4(px[0], px[1], px[2], hr_, hz, hn, state, h)
                     state = h;
+                    if (qs >= 0 && a.saved) {   // {r, z, n, hn, h}: the same expressions as in the cell, so the same bits
+                        float4 r4, z4, n4;
+                        GRU_GATES4(px[0], px[1], px[2], hr_, hz, hn, r4, z4, n4)
+                        float* sp = a.saved + pos * (5 * H) + u;
+                        st4(sp, r4); st4(sp + H, z4); st4(sp + 2 * H, n4); st4(sp + 3 * H, hn); st4(sp + 4 * H, h);
+                    }
                 }
                 if (qs >= 0 && pt == g.p0 + ps - 1) st4(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
                 constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
@@ -1458,19 +1464,19 @@ extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* 
 }
 
 extern "C" int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                              int n_calls, int segments, int warmup, float* h_emit, float* work,
-                                              float* seam_err, icrl_stream_t stream) {
+                                              int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                                              float* work, float* seam_err, icrl_stream_t stream) {
     ChainArgs a;
     if (int rc = make_geom("icrl_gru_chain_fwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && b_hh && h_emit && work && seam_err, "icrl_gru_chain_fwd_seg_persist: null pointer");
-    ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(b_hh) && aligned16(h_emit) && aligned16(work),
-                 "icrl_gru_chain_fwd_seg_persist: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(b_hh) && aligned16(h_emit) && aligned16(saved) &&
+                 aligned16(work), "icrl_gru_chain_fwd_seg_persist: buffers must be 16-byte aligned");
     ICRL_REQUIRE(icrl_chain_pair_supported(segments),
                  "icrl_gru_chain_fwd_seg_persist: %d segments need more workgroups than the device has CUs; its "
                  "workgroups wait for each other and must all be resident", segments);
     hipStream_t st = icrl::as_stream(stream);
     ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
-    a.xproj = xproj; a.w_hh = w_hh; a.b_hh = b_hh; a.saved = nullptr; a.h_emit = h_emit; a.state_in = nullptr;
+    a.xproj = xproj; a.w_hh = w_hh; a.b_hh = b_hh; a.saved = saved; a.h_emit = h_emit; a.state_in = nullptr;
     unsigned* abort_w = nullptr;
     if (int rc = solo_persist(a, 3, work, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(a.g.K * H)), dim3(256), 0, st, a.seam_a, a.seam_b, a.g, H, seam_err);

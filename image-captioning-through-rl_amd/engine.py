@@ -497,7 +497,8 @@ class A2CEngine:
         w_ih, w_hh = R["rewrnn.gru.weight_ih_l0"], R["rewrnn.gru.weight_hh_l0"]
         if plan_f[0] == "segmented":
             hip.gru_chain_fwd_seg(ws["XP"], w_hh, R["rewrnn.gru.bias_hh_l0"], n, l_cols, 1, plan_f[1], plan_f[2],
-                                  ws["hr"], ws["work"], ws["seam"][2:4], saved=ws["saved"])
+                                  ws["hr"], ws["work"], ws["seam"][2:4], saved=ws["saved"],
+                                  persistent=self.persistent and hip.chain_pair_supported(plan_f[1]))
         else:
             hip.gru_chain_fwd(ws["XP"], w_hh, R["rewrnn.gru.bias_hh_l0"], n, l_cols, 1, ws["hr"], ws["sync"],
                               ws["status"][0:1], saved=ws["saved"])

@@ -31,7 +31,7 @@ SIGNATURES = {
     "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_supported": (c_int, [c_int]),
     "icrl_lstm_chain_fwd_seg_persist": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_gru_chain_fwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_fwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 7 + [c_vp] * 8),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
@@ -442,19 +442,12 @@ def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, sa
 
 def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err, saved=None,
                       persistent=False):
-    """persistent: all steps in one launch (needs chain_pair_supported(segments)); it keeps no activations,
-    so it is used only when `saved` is None."""
+    """persistent: all steps in one launch (needs chain_pair_supported(segments))."""
     _chain_shapes("gru_chain_fwd_seg", n, p0, n_calls, 3, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=5,
                   work=work, segments=segments)
-    if persistent and saved is None:
-        with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
-            rc = load().icrl_gru_chain_fwd_seg_persist(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0,
-                                                       n_calls, segments, warmup, _ptr(_f32c(h_emit)),
-                                                       _ptr(_f32c(work)), _ptr(seam_err), _stream())
-        _check(rc, "icrl_gru_chain_fwd_seg_persist")
-        return
+    fn = load().icrl_gru_chain_fwd_seg_persist if persistent else load().icrl_gru_chain_fwd_seg
     with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
-        rc = load().icrl_gru_chain_fwd_seg(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
+        rc = fn(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
                                            segments, warmup, _ptr(_f32c(h_emit)), _ptr(saved), _ptr(_f32c(work)),
                                            _ptr(seam_err), _stream())
     _check(rc, "icrl_gru_chain_fwd_seg")

@@ -232,16 +232,16 @@ int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const flo
 /* One forward chain alone in the same persistent launch (the look-ahead decoder's value calls,
  * trainers.py:73-105, and the pre-training loops, trainers.py:125-199, run one chain at a time):
  * icrl_lstm_chain_fwd_seg / icrl_gru_chain_fwd_seg (models.py:133, 140-143 / 226, 231-233) with the same
- * arguments and the same results bit for bit, without a kernel boundary per step; the GRU variant keeps no
- * activations (no `saved`), and state_in needs warmup >= 1.  Needs icrl_chain_pair_supported(segments); a
+ * arguments and the same results bit for bit, without a kernel boundary per step; state_in needs
+ * warmup >= 1.  Needs icrl_chain_pair_supported(segments); a
  * hand-off time-out sets seam_err[0] = +inf. */
 int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
                                     int segments, int warmup, float* h_emit, float* saved,
                                     const float* state_in, float* work, float* seam_err,
                                     icrl_stream_t stream);
 int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                   int n_calls, int segments, int warmup, float* h_emit, float* work,
-                                   float* seam_err, icrl_stream_t stream);
+                                   int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                                   float* work, float* seam_err, icrl_stream_t stream);
 
 /* icrl_lstm_chain_bwd_seg (the BPTT of models.py:140-143's recurrence) as ONE persistent
  * launch: same arguments, same results bit for bit, no kernel boundary per step.  Needs

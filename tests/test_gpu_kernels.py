@@ -360,6 +360,9 @@ def test_persistent_chains_equal_the_per_step_launches(n, p0, calls, segs, warm)
         assert (err_v[0].item(), err_r[0].item()) == ref_err
         assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
     # each forward chain alone in the persistent launch, the LSTM one also from a given start state
+    pos_r = n * sum(p0 + 1 + s for s in range(calls))
+    gsaved_s = torch.zeros(pos_r, 5, H, device="cuda")
+    hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm_r, torch.zeros_like(g_s), work_r, err_r, saved=gsaved_s)
     state = dev(rnd(rs, 2 * H, scale=0.3))
     h_i, saved_i = torch.zeros_like(h_s), torch.zeros_like(saved_s)
     hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_i, saved_i, work_v, err_v, state_in=state)
@@ -369,10 +372,13 @@ def test_persistent_chains_equal_the_per_step_launches(n, p0, calls, segs, warm)
     for _ in range(2):
         h_p, saved_p, g_p = torch.zeros_like(h_s), torch.zeros_like(saved_s), torch.zeros_like(g_s)
         hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_p, saved_p, work_v, err_v, persistent=True)
-        hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm_r, g_p, work_r, err_r, persistent=True)
+        gsaved_p = torch.zeros_like(gsaved_s)
+        hip.gru_chain_fwd_seg(xg, wg, bg, n, p0 + 1, calls, segs, warm_r, g_p, work_r, err_r, saved=gsaved_p,
+                              persistent=True)
         torch.cuda.synchronize()
         assert (err_v[0].item(), err_r[0].item()) == ref_err
         assert torch.equal(h_p, h_s) and torch.equal(saved_p, saved_s) and torch.equal(g_p, g_s)
+        assert torch.equal(gsaved_p, gsaved_s)
         hip.lstm_chain_fwd_seg(xv, wv, n, p0, calls, segs, warm, h_p, saved_p, work_v, err_v, state_in=state,
                                persistent=True)
         torch.cuda.synchronize()
