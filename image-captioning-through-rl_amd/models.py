@@ -182,9 +182,9 @@ class ValueNetworkRNN(nn.Module):
         it does when the decoder scores one candidate extension after the other) as ONE chain: the calls'
         columns are stacked, the chain keeps every position's h, and each call's last column is read back
         from there.  Long chains run segment-parallel from the carried state, under the seam check.
-        Returns the list of [N, H] outputs."""
+        Returns the [calls, N, H] outputs (indexing it gives the list the separate calls would return)."""
         if self.per_sample:
-            return [self.forward_columns(tok) for tok in tok_list]
+            return torch.stack([self.forward_columns(tok) for tok in tok_list])
         dev = self.lstm.weight_hh_l0.device
         p, n = tok_list[0].shape
         calls = len(tok_list)
@@ -216,8 +216,7 @@ class ValueNetworkRNN(nn.Module):
             if status.item() != 0:
                 raise RuntimeError("value LSTM chain kernel timed out")
         self.hidden_cell = (saved[-1, 5].view(1, 1, H).clone(), saved[-1, 4].view(1, 1, H).clone())
-        by_call = saved.view(calls, p, n, 6, H)
-        return [by_call[c, p - 1, :, 5, :].contiguous() for c in range(calls)]
+        return saved.view(calls, p, n, 6, H)[:, p - 1, :, 5, :].contiguous()
 
     def forward(self, captions):
         """captions [N] -> [N,1,H] (models.py:130-135)."""
@@ -267,13 +266,13 @@ class ValueNetwork(nn.Module):
         toks = [torch.as_tensor(c, device=dev).long().t().contiguous() for c in captions_list]
         u = torch.empty(n, 512, device=dev)
         hip.gemm(feats, self.linear1.weight[:, :f], u, bias=self.linear1.bias)
-        out = []
-        for hs in self.valrnn.forward_columns_many(toks):
-            y, values = torch.empty(n, 512, device=dev), torch.empty(n, device=dev)
-            hip.gemm(hs, self.linear1.weight[:, f:], y)
-            hip.value_head_fwd(y, u, self.linear2.weight, self.linear2.bias, n, n, values)
-            out.append(values.view(n, 1))
-        return out
+        hs = self.valrnn.forward_columns_many(toks)            # [calls, N, 512]
+        calls = hs.shape[0]
+        # the head for all calls at once: its rows do not depend on each other
+        y, values = torch.empty(calls * n, 512, device=dev), torch.empty(calls * n, device=dev)
+        hip.gemm(hs.view(calls * n, 512), self.linear1.weight[:, f:], y)
+        hip.value_head_fwd(y, u, self.linear2.weight, self.linear2.bias, calls * n, n, values)
+        return [values[c * n:(c + 1) * n].view(n, 1) for c in range(calls)]
 
 
 class RewardNetworkRNN(nn.Module):
