@@ -107,10 +107,11 @@ def GenerateCaptionsWithActorCriticLookAhead(features, captions, policy_network,
             for i in range(beamSize):
                 extensions.append((torch.cat((cand, top_words[:, i:i + 1]), dim=1), cand_score, top_vals[:, i:i + 1]))
         values = value_network.forward_many(feats, [e[0] for e in extensions])
-        next_candidates = []
-        for (cap, cand_score, top_val), value in zip(extensions, values):
-            score_delta = 0.6 * value + 0.4 * torch.log(top_val)
-            next_candidates.append((cap, cand_score - score_delta))
+        # the score update of all extensions at once (the same elementwise expressions, so the same bits)
+        prev = torch.stack([s if torch.is_tensor(s) else torch.full_like(values[0], float(s)) for _, s, _ in extensions])
+        score_delta = 0.6 * torch.stack(values) + 0.4 * torch.log(torch.stack([t for _, _, t in extensions]))
+        scores = prev - score_delta
+        next_candidates = [(ext[0], scores[j]) for j, ext in enumerate(extensions)]
         means = torch.stack([c[1].mean() for c in next_candidates]).tolist()   # one read-back per step
         order = sorted(range(len(next_candidates)), key=lambda j: means[j])
         candidates = [next_candidates[j] for j in order[:beamSize]]
