@@ -191,8 +191,17 @@ class ValueNetworkRNN(nn.Module):
         tok_all = torch.cat([tok.reshape(-1) for tok in tok_list])
         positions = calls * p * n
         xproj = torch.empty(positions, 4 * H, device=dev)
-        hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, xproj, a_rows=tok_all,
-                 bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
+        vocab = self.caption_embedding.weight.shape[0]
+        if positions > 2 * vocab:
+            # more positions than words (the decoder's 25 extensions repeat their prefixes): the input side of
+            # every WORD once, then a row gather - row by row the same sums as the direct product
+            table = torch.empty(vocab, 4 * H, device=dev)
+            hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, table, bias=self.lstm.bias_ih_l0,
+                     bias2=self.lstm.bias_hh_l0)
+            hip.gather_rows(table, tok_all, 1, positions, xproj)
+        else:
+            hip.gemm(self.caption_embedding.weight, self.lstm.weight_ih_l0, xproj, a_rows=tok_all,
+                     bias=self.lstm.bias_ih_l0, bias2=self.lstm.bias_hh_l0)
         state = torch.cat((self.hidden_cell[0].reshape(-1), self.hidden_cell[1].reshape(-1))).to(dev).contiguous()
         saved = torch.empty(positions, 6, H, device=dev)
         h_emit = torch.empty(1, n, H, device=dev)
