@@ -1315,23 +1315,59 @@ int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out) {
 
 extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64_t)segments * 16 * H; }
 
-extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
-                                       int segments, int warmup, float* h_emit, float* saved,
-                                       const float* state_in, float* work, float* seam_err, icrl_stream_t stream) {
+namespace {
+// icrl_lstm_chain_fwd_seg on the workspace `work` (the caller's, or this library's static scratch array)
+int lstm_fwd_seg_on(const char* who, const float* xproj, const float* w_hh, int N, int p0, int n_calls, int segments,
+                    int warmup, float* h_emit, float* saved, const float* state_in, float* work, float* seam_err,
+                    hipStream_t st) {
     Geom g;
-    if (int rc = make_geom("icrl_lstm_chain_fwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
-    ICRL_REQUIRE(xproj && w_hh && h_emit && work && seam_err, "icrl_lstm_chain_fwd_seg: null pointer");
-    ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(h_emit) && aligned16(saved) && aligned16(work),
-                 "icrl_lstm_chain_fwd_seg: buffers must be 16-byte aligned");
-    hipStream_t st = icrl::as_stream(stream);
+    if (int rc = make_geom(who, N, p0, n_calls, segments, warmup, g)) return rc;
+    ICRL_REQUIRE(xproj && w_hh && h_emit && work && seam_err, "%s: null pointer", who);
+    ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(h_emit) && aligned16(saved) && aligned16(work) &&
+                 aligned16(state_in), "%s: buffers must be 16-byte aligned", who);
     const int64_t kh = (int64_t)g.K * H;
     ICRL_HIP(hipMemsetAsync(seam_err, 0, sizeof(float), st));
-    ICRL_REQUIRE(aligned16(state_in), "icrl_lstm_chain_fwd_seg: buffers must be 16-byte aligned");
     if (int rc = fwd_steps_lstm(g, xproj, w_hh, h_emit, saved, work, state_in, st)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(g.K * 2 * H)), dim3(256), 0, st, work + 4 * kh, work + 6 * kh,
                        g, 2 * H, seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
+}
+
+// Scratch of the entry point that allocates nothing: the segment workspace (state double buffers, seam
+// records) for up to STATIC_MAX_SEGMENTS segments, 16 * 512 floats each = 4 MiB, resident on every GPU the
+// library runs on until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; every use of its memory goes through the per-device address kept below.
+constexpr int STATIC_MAX_SEGMENTS = 128;
+constexpr int STATIC_MAX_DEVICES = 64;
+static __device__ __align__(256) float scratch[(size_t)STATIC_MAX_SEGMENTS * 16 * H];
+float* scratch_of_device[STATIC_MAX_DEVICES];   // zero-initialised; set once per device, that device current
+}  // namespace
+
+extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+                                       int segments, int warmup, float* h_emit, float* saved,
+                                       const float* state_in, float* work, float* seam_err, icrl_stream_t stream) {
+    return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg", xproj, w_hh, N, p0, n_calls, segments, warmup, h_emit, saved,
+                           state_in, work, seam_err, icrl::as_stream(stream));
+}
+
+extern "C" int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+                                              int segments, int warmup, float* h_emit, float* saved,
+                                              const float* state_in, float* seam_err, icrl_stream_t stream) {
+    ICRL_REQUIRE(segments <= STATIC_MAX_SEGMENTS,
+                 "icrl_lstm_chain_fwd_seg_static: %d segments exceed the static workspace (at most %d); use "
+                 "icrl_lstm_chain_fwd_seg with a workspace of your own", segments, STATIC_MAX_SEGMENTS);
+    int dev = -1;
+    ICRL_HIP(hipGetDevice(&dev));
+    ICRL_REQUIRE(dev >= 0 && dev < STATIC_MAX_DEVICES, "icrl_lstm_chain_fwd_seg_static: device %d not supported", dev);
+    if (scratch_of_device[dev] == nullptr) {   // first call on this device (it is the current one)
+        float* ptr = nullptr;
+        ICRL_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        ICRL_REQUIRE(ptr != nullptr, "icrl_lstm_chain_fwd_seg_static: no address for the static workspace");
+        scratch_of_device[dev] = ptr;
+    }
+    return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg_static", xproj, w_hh, N, p0, n_calls, segments, warmup, h_emit,
+                           saved, state_in, scratch_of_device[dev], seam_err, icrl::as_stream(stream));
 }
 
 extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,

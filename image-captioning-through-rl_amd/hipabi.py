@@ -26,6 +26,7 @@ SIGNATURES = {
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_lstm_chain_fwd_seg_static": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_masked_nll": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_mse_loss": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -438,6 +439,17 @@ def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, sa
                                             _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(_f32c(work)),
                                             _ptr(seam_err), _stream())
     _check(rc, "icrl_lstm_chain_fwd_seg")
+
+
+def lstm_chain_fwd_seg_static(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, seam_err, state_in=None):
+    """lstm_chain_fwd_seg on the library's static workspace (at most 128 segments): no allocation, no
+    workspace argument.  Calls on one GPU share that workspace and must not overlap."""
+    _chain_shapes("lstm_chain_fwd_seg_static", n, p0, n_calls, 4, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved,
+                  slots=6)
+    rc = load().icrl_lstm_chain_fwd_seg_static(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, segments, warmup,
+                                               _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(seam_err),
+                                               _stream())
+    _check(rc, "icrl_lstm_chain_fwd_seg_static")
 
 
 def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err, saved=None,

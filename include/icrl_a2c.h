@@ -195,6 +195,17 @@ int64_t icrl_chain_seg_workspace_floats(int segments);
 int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
                             int segments, int warmup, float* h_emit, float* saved, const float* state_in,
                             float* work, float* seam_err, icrl_stream_t stream);
+/* icrl_lstm_chain_fwd_seg for callers that cannot allocate or carry a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * Same arguments minus `work`, same kernels and the same results bit for bit; the segment workspace is a
+ * static device array inside the library (4 MiB per GPU, held until the process ends), so segments is
+ * limited to 128 and larger values are rejected with ICRL_ERR_ARG.  The call makes no hipMalloc / hipFree
+ * (its first call on a device looks the array's address up once).  Every call on one GPU shares that
+ * array: calls that overlap on one GPU (two streams, two host threads) race; calls in stream order are
+ * safe, whatever their sizes. */
+int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+                                   int segments, int warmup, float* h_emit, float* saved,
+                                   const float* state_in, float* seam_err, icrl_stream_t stream);
 /* saved (may be NULL): the GRU chain's activations {r, z, n, hn, h}, 5*512 floats per position, as
  * icrl_gru_chain_fwd keeps them for icrl_gru_chain_bwd. */
 int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
