@@ -133,7 +133,7 @@ def main():
 
     # per-kernel accounting from the HIP events recorded on each launch's own stream
     acc = {}
-    for kind, work, e0, e1, nbytes in prof:
+    for kind, work, e0, e1, nbytes, _steps, _flops in prof:
         a = acc.setdefault(kind, [0.0, 0.0, 0, 0.0])
         a[0] += work
         a[1] += e0.elapsed_time(e1) * 1e-3

@@ -678,7 +678,8 @@ constexpr unsigned long long SPIN_LIMIT = 2000000ull;  // 20 ms of the 100 MHz w
 
 struct ChainArgs {
     const float* xproj; const float* w_hh; const float* b_hh;
-    const float* state_in;    // {h, c} the chain starts from, or null (LSTM chain only)
+    const float* state_in;    // {h, c} (GRU: {h}) the chain starts from, or null
+    int state_stride;         // floats between the start states of consecutive segments; 0: one state for the chain
     float* hb;                // [2][K][H] exchanged state
     float* saved; float* h_emit; float* seam_a; float* seam_b;
     unsigned* flags;          // [row tiles][16]
@@ -893,11 +894,15 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
 
         if (st != 0) {
             float4 h = zero4();
+            // where a segment's final state is recorded: with the next segment's seam, or (segments that all
+            // replay the same positions) under its own index
+            const int rec = g.stride == 0 ? j : j + 1;
             if (st == 1) {
                 state = zero4();
-                if (G == 4 && a.state_in != nullptr && pos == -1) {   // the step before the chain's first position
-                    h = ld4(a.state_in + u);
-                    state = ld4(a.state_in + H + u);
+                if (a.state_in != nullptr && pos == -1) {   // the step before the chain's first position
+                    const float* si = a.state_in + (int64_t)j * a.state_stride;
+                    h = ld4(si + u);
+                    state = (G == 4) ? ld4(si + H + u) : h;
                 }
             } else {
                 const float* pr = P + rr * PLD + uq;
@@ -912,7 +917,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                         st4(sp, gi); st4(sp + H, gf); st4(sp + 2 * H, gg); st4(sp + 3 * H, go); st4(sp + 4 * H, c); st4(sp + 5 * H, h);
                     }
                     if (qs == -1) st4(a.seam_a + (int64_t)j * 2 * H + H + u, c);
-                    if (qs == g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
+                    if (qs == g.Ls - 1 && rec < g.K) st4(a.seam_b + (int64_t)rec * 2 * H + H + u, c);
                 } else {
                     const float4 hr_ = add4(sum_partials(pr), bias[0]), hz = add4(sum_partials(pr + 32 * PLD), bias[1]);
                     const float4 hn = add4(sum_partials(pr + 64 * PLD), bias[G == 3 ? 2 : 0]);
@@ -925,10 +930,10 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
                         st4(sp, r4); st4(sp + H, z4); st4(sp + 2 * H, n4); st4(sp + 3 * H, hn); st4(sp + 4 * H, h);
                     }
                 }
-                if (qs >= 0 && pt == g.p0 + ps - 1) st4(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
+                if (qs >= 0 && a.h_emit != nullptr && pt == g.p0 + ps - 1) st4(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
                 constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
                 if (qs == -1) st4(a.seam_a + (int64_t)j * SW + u, h);
-                if (qs == g.Ls - 1 && j + 1 < g.K) st4(a.seam_b + (int64_t)(j + 1) * SW + u, h);
+                if (qs == g.Ls - 1 && rec < g.K) st4(a.seam_b + (int64_t)rec * SW + u, h);
             }
             // the exchanged copy of h: write-through, 16 bytes per lane
             __builtin_amdgcn_raw_buffer_store_b128(as_u4(h), rs, (j * H + u) * 4, nxt * g.K * H * 4, SC1);
@@ -1317,11 +1322,12 @@ extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64
 
 namespace {
 // icrl_lstm_chain_fwd_seg on the workspace `work` (the caller's, or this library's static scratch array)
-int lstm_fwd_seg_on(const char* who, const float* xproj, const float* w_hh, int N, int p0, int n_calls, int segments,
+int lstm_fwd_seg_on(const char* who, const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
+                    int segments,
                     int warmup, float* h_emit, float* saved, const float* state_in, float* work, float* seam_err,
                     hipStream_t st) {
     Geom g;
-    if (int rc = make_geom(who, N, p0, n_calls, segments, warmup, g)) return rc;
+    if (int rc = make_geom(who, N, p0, n_calls, full_calls, segments, warmup, g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && h_emit && work && seam_err, "%s: null pointer", who);
     ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(h_emit) && aligned16(saved) && aligned16(work) &&
                  aligned16(state_in), "%s: buffers must be 16-byte aligned", who);
@@ -1344,14 +1350,14 @@ static __device__ __align__(256) float scratch[(size_t)STATIC_MAX_SEGMENTS * 16 
 float* scratch_of_device[STATIC_MAX_DEVICES];   // zero-initialised; set once per device, that device current
 }  // namespace
 
-extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
                                        int segments, int warmup, float* h_emit, float* saved,
                                        const float* state_in, float* work, float* seam_err, icrl_stream_t stream) {
-    return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg", xproj, w_hh, N, p0, n_calls, segments, warmup, h_emit, saved,
-                           state_in, work, seam_err, icrl::as_stream(stream));
+    return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg", xproj, w_hh, N, p0, n_calls, full_calls, segments, warmup, h_emit,
+                           saved, state_in, work, seam_err, icrl::as_stream(stream));
 }
 
-extern "C" int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+extern "C" int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
                                               int segments, int warmup, float* h_emit, float* saved,
                                               const float* state_in, float* seam_err, icrl_stream_t stream) {
     ICRL_REQUIRE(segments <= STATIC_MAX_SEGMENTS,
@@ -1366,15 +1372,15 @@ extern "C" int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w
         ICRL_REQUIRE(ptr != nullptr, "icrl_lstm_chain_fwd_seg_static: no address for the static workspace");
         scratch_of_device[dev] = ptr;
     }
-    return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg_static", xproj, w_hh, N, p0, n_calls, segments, warmup, h_emit,
-                           saved, state_in, scratch_of_device[dev], seam_err, icrl::as_stream(stream));
+    return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg_static", xproj, w_hh, N, p0, n_calls, full_calls, segments, warmup,
+                           h_emit, saved, state_in, scratch_of_device[dev], seam_err, icrl::as_stream(stream));
 }
 
 extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                      int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                                      int n_calls, int full_calls, int segments, int warmup, float* h_emit, float* saved,
                                       float* work, float* seam_err, icrl_stream_t stream) {
     Geom g;
-    if (int rc = make_geom("icrl_gru_chain_fwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
+    if (int rc = make_geom("icrl_gru_chain_fwd_seg", N, p0, n_calls, full_calls, segments, warmup, g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && b_hh && h_emit && work && seam_err, "icrl_gru_chain_fwd_seg: null pointer");
     ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(b_hh) && aligned16(h_emit) && aligned16(work),
                  "icrl_gru_chain_fwd_seg: buffers must be 16-byte aligned");
@@ -1390,10 +1396,10 @@ extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, con
 }
 
 extern "C" int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
-                                       int n_calls, int segments, int warmup, float* dgates, float* work,
+                                       int n_calls, int full_calls, int segments, int warmup, float* dgates, float* work,
                                        float* seam_err, icrl_stream_t stream) {
     Geom g;
-    if (int rc = make_geom("icrl_lstm_chain_bwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
+    if (int rc = make_geom("icrl_lstm_chain_bwd_seg", N, p0, n_calls, full_calls, segments, warmup, g)) return rc;
     ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && seam_err, "icrl_lstm_chain_bwd_seg: null pointer");
     ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),
                  "icrl_lstm_chain_bwd_seg: buffers must be 16-byte aligned");
@@ -1411,7 +1417,7 @@ extern "C" int icrl_gru_chain_bwd_seg(const float* w_hh, const float* saved, con
                                       int n_calls, int segments, int warmup, float* dgates_x, float* dgates_h,
                                       float* work, float* seam_err, icrl_stream_t stream) {
     Geom g;
-    if (int rc = make_geom("icrl_gru_chain_bwd_seg", N, p0, n_calls, segments, warmup, g)) return rc;
+    if (int rc = make_geom("icrl_gru_chain_bwd_seg", N, p0, n_calls, 0, segments, warmup, g)) return rc;
     ICRL_REQUIRE(w_hh && saved && d_emit && dgates_x && dgates_h && work && seam_err,
                  "icrl_gru_chain_bwd_seg: null pointer");
     ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates_x) &&
@@ -1444,17 +1450,18 @@ extern "C" int icrl_chain_pair_supported(int segments) {
 
 extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
                                        const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
-                                       int n_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
-                                       float* saved_v, float* h_emit_r, float* work_v, float* work_r,
+                                       int n_calls, int full_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
+                                       float* saved_v, float* h_emit_r, float* saved_r, float* work_v, float* work_r,
                                        float* seam_err_v, float* seam_err_r, icrl_stream_t stream) {
-    ChainArgs v, r;
-    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_v, n_calls, segments, warmup_v, v.g)) return rc;
-    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_r, n_calls, segments, warmup_r, r.g)) return rc;
+    ChainArgs v{}, r{};
+    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_v, n_calls, full_calls, segments, warmup_v, v.g)) return rc;
+    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_r, n_calls, full_calls, segments, warmup_r, r.g)) return rc;
     ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r &&
                  seam_err_v && seam_err_r, "icrl_chain_pair_fwd_seg: null pointer");
     ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(xproj_r) && aligned16(w_hh_r) &&
                  aligned16(b_hh_r) && aligned16(h_emit_v) && aligned16(saved_v) && aligned16(h_emit_r) &&
-                 aligned16(work_v) && aligned16(work_r), "icrl_chain_pair_fwd_seg: buffers must be 16-byte aligned");
+                 aligned16(saved_r) && aligned16(work_v) && aligned16(work_r),
+                 "icrl_chain_pair_fwd_seg: buffers must be 16-byte aligned");
     ICRL_REQUIRE(icrl_chain_pair_supported(segments),
                  "icrl_chain_pair_fwd_seg: %d segments need more workgroups than the device has CUs; its workgroups "
                  "wait for each other and must all be resident", segments);
@@ -1462,7 +1469,7 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
     ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
     v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v; v.state_in = nullptr;
-    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = nullptr; r.h_emit = h_emit_r; r.state_in = nullptr;
+    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = saved_r; r.h_emit = h_emit_r; r.state_in = nullptr;
     unsigned* abort_w = nullptr;
     if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(v.g.K * 2 * H)), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
@@ -1474,12 +1481,12 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     return ICRL_OK;
 }
 
-extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
                                                int segments, int warmup, float* h_emit, float* saved,
                                                const float* state_in, float* work, float* seam_err,
                                                icrl_stream_t stream) {
-    ChainArgs a;
-    if (int rc = make_geom("icrl_lstm_chain_fwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
+    ChainArgs a{};
+    if (int rc = make_geom("icrl_lstm_chain_fwd_seg_persist", N, p0, n_calls, full_calls, segments, warmup, a.g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && h_emit && work && seam_err, "icrl_lstm_chain_fwd_seg_persist: null pointer");
     ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(h_emit) && aligned16(saved) && aligned16(work) &&
                  aligned16(state_in), "icrl_lstm_chain_fwd_seg_persist: buffers must be 16-byte aligned");
@@ -1500,10 +1507,10 @@ extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* 
 }
 
 extern "C" int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                              int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                                              int n_calls, int full_calls, int segments, int warmup, float* h_emit, float* saved,
                                               float* work, float* seam_err, icrl_stream_t stream) {
-    ChainArgs a;
-    if (int rc = make_geom("icrl_gru_chain_fwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
+    ChainArgs a{};
+    if (int rc = make_geom("icrl_gru_chain_fwd_seg_persist", N, p0, n_calls, full_calls, segments, warmup, a.g)) return rc;
     ICRL_REQUIRE(xproj && w_hh && b_hh && h_emit && work && seam_err, "icrl_gru_chain_fwd_seg_persist: null pointer");
     ICRL_REQUIRE(aligned16(xproj) && aligned16(w_hh) && aligned16(b_hh) && aligned16(h_emit) && aligned16(saved) &&
                  aligned16(work), "icrl_gru_chain_fwd_seg_persist: buffers must be 16-byte aligned");
@@ -1522,10 +1529,10 @@ extern "C" int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w
 }
 
 extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const float* d_emit, int N,
-                                               int p0, int n_calls, int segments, int warmup, float* dgates,
+                                               int p0, int n_calls, int full_calls, int segments, int warmup, float* dgates,
                                                float* work, float* seam_err, icrl_stream_t stream) {
-    BwdArgs a;
-    if (int rc = make_geom("icrl_lstm_chain_bwd_seg_persist", N, p0, n_calls, segments, warmup, a.g)) return rc;
+    BwdArgs a{};
+    if (int rc = make_geom("icrl_lstm_chain_bwd_seg_persist", N, p0, n_calls, full_calls, segments, warmup, a.g)) return rc;
     ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && seam_err, "icrl_lstm_chain_bwd_seg_persist: null pointer");
     ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),
                  "icrl_lstm_chain_bwd_seg_persist: buffers must be 16-byte aligned");
@@ -1544,6 +1551,107 @@ extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* s
     return ICRL_OK;
 }
 
+// ------------------------------------------------------------------ may the replays be left out?
+// A chain evaluated with full_calls < n_calls leaves out, for every call s >= full_calls, the replay of the
+// inputs of call s-1 that the reference runs before the call's new column.  That is right exactly when such
+// a replay, started from the state call s-1 ended in, comes back to that same state.  This entry point runs
+// the replays' first `steps` positions for all those calls side by side (one row per call, each from its own
+// start state, all over the same inputs: the persistent pair launch with stride 0) and reports how far each
+// row's state then is from the state the last fully walked call had at that position: once the two
+// trajectories meet they stay together, since from there on they see the same inputs.
+__global__ __launch_bounds__(256) void replay_states(const float* __restrict__ saved, int slots, int h_slot, int c_slot,
+                                                     int64_t first_pos, int64_t pos_step, int rows,
+                                                     float* __restrict__ out) {
+    const int sw = c_slot >= 0 ? 2 * H : H;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * sw; e += gridDim.x * 256) {
+        const int j = e / sw, k = e % sw;
+        const int64_t pos = first_pos + (int64_t)j * pos_step;
+        out[e] = saved[(pos * slots + (k < H ? h_slot : c_slot)) * H + (k & (H - 1))];
+    }
+}
+
+__global__ __launch_bounds__(256) void replay_compare(const float* __restrict__ fin, const float* __restrict__ saved,
+                                                      int slots, int h_slot, int c_slot, int64_t target_pos, int rows,
+                                                      float* __restrict__ err) {
+    __shared__ float red[4];
+    const int sw = c_slot >= 0 ? 2 * H : H;
+    float d = 0.f;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < rows * sw; e += gridDim.x * 256) {
+        const int k = e % sw;
+        const float b = saved[(target_pos * slots + (k < H ? h_slot : c_slot)) * H + (k & (H - 1))];
+        float v = fabsf(fin[e] - b) / fmaxf(1.f, fabsf(b));
+        if (!(v == v)) v = INFINITY;
+        d = fmaxf(d, v);
+    }
+    d = wave_max(d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (d > 0.f) atomic_max_nonneg(err, d);
+    }
+}
+
+namespace {
+// geometry of the replay rows: `rows` chains that all walk positions 0 .. steps-1 (one warm-up step that only
+// loads the row's start state)
+void replay_geom(Geom& g, int N, int rows, int steps) {
+    const int cols = (steps + N - 1) / N + 1;   // one column more than the rows reach: nothing is ever emitted
+    g.n = N; g.p0 = cols; g.n_calls = 1; g.fc = 1; g.c0 = cols;
+    g.total = steps; g.K = rows; g.Ls = steps; g.W = 1; g.stride = 0;
+}
+}  // namespace
+
+extern "C" int icrl_chain_pair_replay_check(const float* xproj_v, const float* w_hh_v, const float* saved_v,
+                                            const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
+                                            const float* saved_r, int N, int p0_v, int p0_r, int n_calls,
+                                            int full_calls, int steps, float* work_v, float* work_r, float* err,
+                                            icrl_stream_t stream) {
+    ICRL_REQUIRE(N > 0 && p0_v > 0 && p0_r > 0 && n_calls > 1, "icrl_chain_pair_replay_check: bad shape");
+    ICRL_REQUIRE(full_calls >= 1 && full_calls < n_calls,
+                 "icrl_chain_pair_replay_check: full_calls must be in [1, n_calls): nothing is left out otherwise");
+    const int rows = n_calls - full_calls;
+    const int64_t len_v = (int64_t)(p0_v + full_calls - 1) * N, len_r = (int64_t)(p0_r + full_calls - 1) * N;
+    ICRL_REQUIRE(steps >= 1 && steps <= len_v && steps <= len_r,
+                 "icrl_chain_pair_replay_check: steps must be in [1, %lld], the length of the shortest replay left out",
+                 (long long)std::min(len_v, len_r));
+    ICRL_REQUIRE(xproj_v && w_hh_v && saved_v && xproj_r && w_hh_r && b_hh_r && saved_r && work_v && work_r && err,
+                 "icrl_chain_pair_replay_check: null pointer");
+    ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(saved_v) && aligned16(xproj_r) &&
+                 aligned16(w_hh_r) && aligned16(b_hh_r) && aligned16(saved_r) && aligned16(work_v) && aligned16(work_r),
+                 "icrl_chain_pair_replay_check: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(icrl_chain_pair_supported(rows), "icrl_chain_pair_replay_check: too many rows for this device");
+    hipStream_t st = icrl::as_stream(stream);
+    ChainArgs v{}, r{};
+    replay_geom(v.g, N, rows, steps);
+    replay_geom(r.g, N, rows, steps);
+    const int64_t kh = (int64_t)rows * H;
+    const int c0_v = full_calls * p0_v + full_calls * (full_calls - 1) / 2;
+    const int c0_r = full_calls * p0_r + full_calls * (full_calls - 1) / 2;
+    float* states_v = work_v + 8 * kh;   // [rows][2H]
+    float* states_r = work_r + 8 * kh;   // [rows][H]
+    ICRL_HIP(hipMemsetAsync(err, 0, 2 * sizeof(float), st));
+    // row j stands for call full_calls + j: it starts from the state at the end of the call before it
+    hipLaunchKernelGGL(replay_states, dim3(seam_blocks(rows * 2 * H)), dim3(256), 0, st, saved_v, 6, 5, 4,
+                       (int64_t)c0_v * N - 1, (int64_t)N, rows, states_v);
+    hipLaunchKernelGGL(replay_states, dim3(seam_blocks(rows * H)), dim3(256), 0, st, saved_r, 5, 4, -1,
+                       (int64_t)c0_r * N - 1, (int64_t)N, rows, states_r);
+    v.xproj = xproj_v; v.w_hh = w_hh_v; v.state_in = states_v; v.state_stride = 2 * H;
+    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.state_in = states_r; r.state_stride = H;
+    unsigned* abort_w = nullptr;
+    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
+    // the state the last fully walked call had after the same `steps` inputs
+    const int64_t target_v = ((int64_t)c0_v - (p0_v + full_calls - 1)) * N + steps - 1;
+    const int64_t target_r = ((int64_t)c0_r - (p0_r + full_calls - 1)) * N + steps - 1;
+    hipLaunchKernelGGL(replay_compare, dim3(seam_blocks(rows * 2 * H)), dim3(256), 0, st, v.seam_b, saved_v, 6, 5, 4,
+                       target_v, rows, err);
+    hipLaunchKernelGGL(replay_compare, dim3(seam_blocks(rows * H)), dim3(256), 0, st, r.seam_b, saved_r, 5, 4, -1,
+                       target_r, rows, err + 1);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, err, err + 1);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
 // ------------------------------------------------------------------ every row its own chain
 // The recurrences as a per-image model would run them (the reference's own classes at batch size 1): row i
 // walks its own columns, call after call, from a zero state, independently of the other rows.  The N
@@ -1554,7 +1662,7 @@ extern "C" int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_
                                         int n_calls, int persistent, float* h_emit_v, float* saved_v,
                                         float* h_emit_r, float* work_v, float* work_r, int* status,
                                         icrl_stream_t stream) {
-    ChainArgs v, r;
+    ChainArgs v{}, r{};
     if (int rc = make_geom_rows("icrl_chain_pair_fwd_rows", N, p0_v, n_calls, v.g)) return rc;
     if (int rc = make_geom_rows("icrl_chain_pair_fwd_rows", N, p0_r, n_calls, r.g)) return rc;
     ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r && status,
@@ -1584,7 +1692,7 @@ extern "C" int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_
 extern "C" int icrl_lstm_chain_bwd_rows(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
                                         int n_calls, int persistent, float* dgates, float* work, int* status,
                                         icrl_stream_t stream) {
-    BwdArgs a;
+    BwdArgs a{};
     if (int rc = make_geom_rows("icrl_lstm_chain_bwd_rows", N, p0, n_calls, a.g)) return rc;
     ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && status, "icrl_lstm_chain_bwd_rows: null pointer");
     ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),

@@ -19,29 +19,38 @@ constexpr int PLD = 33;       // padded row of the epilogue exchange tiles
 
 struct Geom {
     int n, p0, n_calls;   // rows per column, columns in the first call, calls
+    int fc, c0;           // calls walked in full, and their columns fc*p0 + fc(fc-1)/2; a later call contributes its last column only
     int64_t total;        // positions in the chain
     int K, Ls, W;         // segments, positions per segment, warm-up steps
-    int stride;           // positions between consecutive steps of a segment: 1, or n when every row is its own chain
+    int stride;           // positions between consecutive steps of a segment: 1; n when every row is its own chain;
+                          // 0 when every "segment" walks the SAME positions 0, 1, 2, ... from a state of its own (replay check)
 };
 
+// Which positions a chain has.  A call s of the reference walks columns 0 .. p0+s-1 of the caption matrix (all
+// n rows of a column, then the next column), so call s+1 first REPLAYS every input of call s from the state
+// call s ended in, and then reads one new column.  A recurrence that forgets ends such a replay in the very
+// state it started from (the one call s ended in), so the replay can be left out: calls fc .. n_calls-1 then
+// contribute only their last column.  fc = n_calls walks every call in full.  Whether the replay may be left
+// out is checked by the caller (icrl_chain_pair_replay_check), never assumed.
+//
 // Position of step q of segment j (0 <= q < Ls: its own positions, q < 0: warm-up before them, q >= Ls:
 // warm-up after them).  stride 1: the batch-1 chain cut into K runs of Ls consecutive positions.
 // stride n: K = n independent chains, one per row, each walking its row's positions column by column.
 __device__ __forceinline__ int64_t seg_pos(const Geom& g, int j, int q) {
-    return g.stride == 1 ? (int64_t)j * g.Ls + q : (int64_t)q * g.n + j;
+    return g.stride == 1 ? (int64_t)j * g.Ls + q : g.stride == 0 ? (int64_t)q : (int64_t)q * g.n + j;
 }
 
 // position -> (call s, column t, row i)
 __device__ __forceinline__ void locate(const Geom& g, int64_t pos, int& s, int& t, int& i) {
+    const int64_t c = pos / g.n;
+    i = (int)(pos - c * g.n);
+    if (c >= g.c0) { s = g.fc + (int)(c - g.c0); t = g.p0 + s - 1; return; }
     int64_t off = 0;
-    for (s = 0; s < g.n_calls - 1; ++s) {
-        const int64_t len = (int64_t)(g.p0 + s) * g.n;
-        if (pos < off + len) break;
-        off += len;
+    for (s = 0; s < g.fc - 1; ++s) {
+        if (c < off + g.p0 + s) break;
+        off += g.p0 + s;
     }
-    const int64_t rem = pos - off;
-    t = (int)(rem / g.n);
-    i = (int)(rem % g.n);
+    t = (int)(c - off);
 }
 
 // The same without a search loop (make_geom bounds the chain below 2^30 positions): the column index
@@ -50,11 +59,12 @@ __device__ __forceinline__ void locate(const Geom& g, int64_t pos, int& s, int& 
 __device__ __forceinline__ void locate_fast(const Geom& g, int pos, int& s, int& t, int& i) {
     const unsigned c = (unsigned)pos / (unsigned)g.n;
     i = pos - (int)(c * (unsigned)g.n);
+    if ((int)c >= g.c0) { s = g.fc + ((int)c - g.c0); t = g.p0 + s - 1; return; }
     const float b = (float)(2 * g.p0 - 1);
     s = (int)((__fsqrt_rn(__fmaf_rn(8.f, (float)c, b * b)) - b) * 0.5f);
-    s = min(s, g.n_calls - 1);
+    s = min(s, g.fc - 1);
     while (s * g.p0 + s * (s - 1) / 2 > (int)c) --s;
-    while (s + 1 <= g.n_calls - 1 && (s + 1) * g.p0 + (s + 1) * s / 2 <= (int)c) ++s;
+    while (s + 1 <= g.fc - 1 && (s + 1) * g.p0 + (s + 1) * s / 2 <= (int)c) ++s;
     t = (int)c - (s * g.p0 + s * (s - 1) / 2);
 }
 
@@ -109,13 +119,20 @@ __device__ __forceinline__ void acc_to_lds(const f32x16& acc, float* tile, int l
 }
 
 
-inline int make_geom(const char* who, int N, int p0, int n_calls, int segments, int warmup, Geom& g) {
+// positions of a chain whose first `fc` calls are walked in full (see Geom)
+inline int64_t chain_columns(int p0, int n_calls, int fc) {
+    return (int64_t)fc * p0 + (int64_t)fc * (fc - 1) / 2 + (n_calls - fc);
+}
+
+// full_calls: 0 or n_calls = every call in full
+inline int make_geom(const char* who, int N, int p0, int n_calls, int full_calls, int segments, int warmup, Geom& g) {
     ICRL_REQUIRE(N > 0 && p0 > 0 && n_calls > 0, "%s: N, p0 and n_calls must be positive", who);
+    ICRL_REQUIRE(full_calls >= 0 && full_calls <= n_calls, "%s: full_calls must be in [0, n_calls]", who);
     ICRL_REQUIRE(segments >= 2 && segments <= 4096 && warmup >= 1, "%s: need 2 <= segments <= 4096, warmup >= 1", who);
     g.n = N; g.p0 = p0; g.n_calls = n_calls;
-    int64_t cols = 0;
-    for (int s = 0; s < n_calls; ++s) cols += p0 + s;
-    g.total = cols * N;
+    g.fc = full_calls == 0 ? n_calls : full_calls;
+    g.c0 = g.fc * p0 + g.fc * (g.fc - 1) / 2;
+    g.total = chain_columns(p0, n_calls, g.fc) * N;
     ICRL_REQUIRE(g.total < (int64_t)1 << 30, "%s: chains of 2^30 or more positions are not supported", who);
     g.K = segments;
     g.Ls = (int)((g.total + segments - 1) / segments);
@@ -129,8 +146,9 @@ inline int make_geom(const char* who, int N, int p0, int n_calls, int segments, 
 inline int make_geom_rows(const char* who, int N, int p0, int n_calls, Geom& g) {
     ICRL_REQUIRE(N > 0 && N <= 4096 && p0 > 0 && n_calls > 0, "%s: need 0 < N <= 4096, p0 > 0, n_calls > 0", who);
     g.n = N; g.p0 = p0; g.n_calls = n_calls;
-    int64_t cols = 0;
-    for (int s = 0; s < n_calls; ++s) cols += p0 + s;
+    g.fc = n_calls;
+    g.c0 = g.fc * p0 + g.fc * (g.fc - 1) / 2;
+    const int64_t cols = chain_columns(p0, n_calls, n_calls);
     g.total = cols * N;
     ICRL_REQUIRE(g.total < (int64_t)1 << 30, "%s: chains of 2^30 or more positions are not supported", who);
     g.K = N; g.Ls = (int)cols; g.W = 0; g.stride = N;

@@ -369,27 +369,37 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- chain helpers
-// out[(t*N+i), :] = sum_{s : p0+s > t} dgates[off(s) + t*N + i, :], off(s) = N*sum_{s'<s}(p0+s')
-__global__ __launch_bounds__(256) void chain_fold_kernel(const float* __restrict__ dg, int n, int p0,
-                                                         int n_calls, int w4, float4* __restrict__ out) {
-    const int cols = p0 + n_calls - 1;
-    const int64_t total = (int64_t)cols * n * w4;
-    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t rowi = e / w4;  // t*N + i
-        const int c = (int)(e % w4);
-        const int t = (int)(rowi / n);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        int64_t off = 0;
-        for (int call = 0; call < n_calls; ++call) {
-            const int len = p0 + call;
-            if (t < len) {
-                const float4 v = reinterpret_cast<const float4*>(dg)[(off + rowi) * w4 + c];
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-            off += (int64_t)len * n;
+// out[(t*N+i), :] = sum over the calls s that hold column t of dgates[position of (s, t, i), :].  The chain is
+// calls 0 .. fc-1 in full (call s: columns 0 .. p0+s-1, its positions starting at column offset
+// s*p0 + s(s-1)/2), then column p0+s-1 alone for each later call s.  One workgroup row per output row
+// (so call and column are uniform and cost scalar arithmetic only), four loads in flight per lane.
+__global__ __launch_bounds__(256) void chain_fold_kernel(const float* __restrict__ dg, int n, int p0, int n_calls, int fc,
+                                                         int w4, float4* __restrict__ out) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= w4) return;
+    const int64_t rowi = blockIdx.x;   // t*N + i
+    const int t = (int)(rowi / n);
+    const int64_t in_col = rowi - (int64_t)t * n;
+    const int c0 = fc * p0 + fc * (fc - 1) / 2;
+    const float4* dg4 = reinterpret_cast<const float4*>(dg) + c;
+    auto col_of = [&](int call) { return (int64_t)call * p0 + (int64_t)call * (call - 1) / 2 + t; };
+    auto ld = [&](int64_t col) { return dg4[(col * n + in_col) * w4]; };
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int first = max(0, t - p0 + 1);   // the first call that holds column t
+    float4 s = zero;
+    if (first >= fc) {                      // a call past the full ones: its single column
+        if (first < n_calls) s = ld((int64_t)c0 + first - fc);
+    } else {
+        for (int call = first; call < fc; call += 4) {
+            const float4 a = ld(col_of(call));
+            const float4 b = call + 1 < fc ? ld(col_of(call + 1)) : zero;
+            const float4 d = call + 2 < fc ? ld(col_of(call + 2)) : zero;
+            const float4 e = call + 3 < fc ? ld(col_of(call + 3)) : zero;
+            s.x += (a.x + b.x) + (d.x + e.x); s.y += (a.y + b.y) + (d.y + e.y);
+            s.z += (a.z + b.z) + (d.z + e.z); s.w += (a.w + b.w) + (d.w + e.w);
         }
-        out[e] = s;
     }
+    out[rowi * w4 + c] = s;
 }
 
 // h_prev[pos,:] = saved[pos-stride, h_slot] (zeros for pos < stride); `slots` x 512 floats per position
@@ -565,13 +575,15 @@ extern "C" int icrl_adam_step(float* param, const float* grad, float* exp_avg, f
     return ICRL_OK;
 }
 
-extern "C" int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
-                                     icrl_stream_t stream) {
-    ICRL_REQUIRE(dgates && out && N > 0 && p0 > 0 && n_calls > 0 && width % 4 == 0,
-                 "icrl_chain_fold_calls: bad argument");
-    const int64_t total = (int64_t)(p0 + n_calls - 1) * N * (width / 4);
-    hipLaunchKernelGGL(chain_fold_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), dgates, N,
-                       p0, n_calls, width / 4, reinterpret_cast<float4*>(out));
+extern "C" int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int full_calls, int width,
+                                     float* out, icrl_stream_t stream) {
+    ICRL_REQUIRE(dgates && out && N > 0 && p0 > 0 && n_calls > 0 && width % 4 == 0 && full_calls >= 0 &&
+                 full_calls <= n_calls, "icrl_chain_fold_calls: bad argument");
+    const int64_t rows = (int64_t)(p0 + n_calls - 1) * N;
+    ICRL_REQUIRE(rows < ((int64_t)1 << 31), "icrl_chain_fold_calls: too many rows");
+    const int w4 = width / 4;
+    hipLaunchKernelGGL(chain_fold_kernel, dim3((unsigned)rows, (w4 + 255) / 256), dim3(256), 0, as_stream(stream), dgates,
+                       N, p0, n_calls, full_calls == 0 ? n_calls : full_calls, w4, reinterpret_cast<float4*>(out));
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -25,6 +25,18 @@ The two recurrences can be evaluated in two ways (``chain_mode``):
     run in one launch, and all steps of the backward chain in another;
   * "auto" (default): segmented for chains of at least 4096 positions, else exact.
 
+Replays left out (``collapse_replays``, default on, batch semantics only).  Call s of the value network walks
+caption columns 0 .. p0+s-1 (models.py:168-169), so call s+1 starts by replaying every input of call s from
+the state call s ended in, and only then reads its one new column; the reward network does the same one
+column further (models.py:254-255).  A recurrence that forgets ends such a replay in the state it started
+from, so the chains walk calls 0 .. fc-1 in full and then one column per later call: about a tenth of the
+positions at batch 512, T = 20, forward and backward (the gate gradients of the short chain are the full
+chain's summed over calls).  Nothing is assumed: beside the backward pass a third stream runs the first
+steps of every replay that was left out, from the state the chain had there, and the step stands only if each
+one has met the trajectory of the last fully walked call to rounding (icrl_chain_pair_replay_check), and if
+the accepted backward warm-up, which bounds how far a gradient reaches, is shorter than the shortest replay
+left out; otherwise the minibatch is redone with more calls in full, in the end with all of them.
+
 ``chain_semantics="per_sample"`` is an explicit change of what is computed, never a default: every
 image owns its recurrent state (the reference's own classes called with one image at a time,
 state kept across the calls of a minibatch), so row i's values and rewards no longer depend on the
@@ -46,7 +58,7 @@ class A2CStepResult:
     rewards [N, S] float32; scalars[0..4] = loss, actor, critic, mean reward, mean adv."""
 
     def __init__(self, tokens, log_probs, values, rewards, scalars, entropy, status, chain_plan=None, reward_plan=None,
-                 status_host=None):
+                 status_host=None, full_calls=None):
         self.tokens, self.log_probs, self.values, self.rewards = tokens, log_probs, values, rewards
         self.scalars, self.entropy, self.status = scalars, entropy, status
         # the status words as read back together with the backward seam check (after every chain kernel of
@@ -55,6 +67,8 @@ class A2CStepResult:
         # (value chain forward, value chain backward), each ("exact",), ("segmented", segments, warmup) or ("rows",)
         self.chain_plan = chain_plan
         self.reward_plan = reward_plan  # the same for the reward chain (forward only)
+        # calls the chains walked in full (= the number of calls unless the later calls' replays were left out)
+        self.full_calls = full_calls
 
     def check(self):
         """Raises if a chain kernel gave up waiting for a peer workgroup.  Synchronises unless the step has
@@ -75,10 +89,11 @@ def _runs_beside(main, cand, cycles=4000000):
     def spin_pair(second):
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record(main)
-        torch.cuda._sleep(cycles)
-        if second is None:
+        with torch.cuda.stream(main):
             torch.cuda._sleep(cycles)
-        else:
+            if second is None:
+                torch.cuda._sleep(cycles)
+        if second is not None:
             with torch.cuda.stream(second):
                 second.wait_event(t0)
                 torch.cuda._sleep(cycles)
@@ -88,6 +103,7 @@ def _runs_beside(main, cand, cycles=4000000):
         t1.record(main)
         t1.synchronize()
         return t0.elapsed_time(t1)
+
     serial = spin_pair(None)
     return spin_pair(cand) < 0.75 * serial
 
@@ -148,11 +164,13 @@ class _WarmupLadder:
 class A2CEngine:
     SEAM_TOL_FWD = 1e-5   # max |state_warm - state_true| / max(1, |state_true|) over h and c
     SEAM_TOL_BWD = 1e-4   # max |d_warm - d_true| / max |d_true| over dh and dc
+    REPLAY_TOL = 1e-5     # a replay that was left out vs the trajectory it must have met: same measure as SEAM_TOL_FWD
+    COLLAPSED_MAX_SEGMENTS = 256   # at most one chain workgroup per CU, so that the replay check's fit beside them
 
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
-                 chain_semantics="batch",
+                 chain_semantics="batch", collapse_replays=True, max_segments=512,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1536, 2048), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -167,7 +185,13 @@ class A2CEngine:
         assert chain_semantics in ("batch", "per_sample")
         self.per_sample = chain_semantics == "per_sample"
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
-        self.fallbacks = 0  # how many times a seam check rejected a segmented attempt
+        self.fallbacks = 0  # how many times a seam or replay check rejected an attempt
+        self.collapse = collapse_replays and not self.per_sample
+        self.max_segments = int(max_segments)
+        # positions a replay must have before it is left out (raised when a replay check fails; decays again)
+        self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
+        self.last_replay = None      # (full_calls, steps, err value chain, err reward chain) of the last step
+        self._check = None           # third stream: the replay check runs beside the backward pass
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
         # on_policy_grads(event): called once per step as soon as the forward pass has been accepted, with
         # the event after which the policy network's gradients are complete; a data-parallel caller starts
@@ -206,22 +230,30 @@ class A2CEngine:
                 assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), k
 
     # ------------------------------------------------------------------ workspaces
+    MIN_REPLAY = 128      # shortest replay, in positions, that is ever left out
+    MAX_SHAPES = 24       # problem shapes whose workspaces are kept (the least recently used one is dropped)
+
     def _buffers(self, n, p0, s):
         key = (n, p0, s)
-        ws = self._ws.get(key)
+        ws = self._ws.pop(key, None)
         if ws is not None:
+            self._ws[key] = ws            # most recently used last
             return ws
+        while len(self._ws) >= self.MAX_SHAPES:
+            self._ws.pop(next(iter(self._ws)))
         dev = self.device
         t_steps, l_cols, lv = p0 - 1 + s, p0 + s, p0 + s - 1
-        tv = n * sum(p0 + k for k in range(s))
+        tv = hip.chain_positions(n, p0, s)
 
         def f32(*shape):
             return torch.empty(*shape, dtype=torch.float32, device=dev)
 
-        ws = dict(tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev), tv=tv,
+        ws = dict(tokT=torch.zeros(l_cols, n, dtype=torch.int64, device=dev), tv=tv, cap_v=0, cap_r=0,
                   scalars=torch.zeros(8, dtype=torch.float32, device=dev),
-                  ctl=torch.zeros(12, dtype=torch.float32, device=dev),   # seam errors [0:6], status words [8:12]
+                  # seam errors [0:6], replay errors [6:8], status words [8:12]
+                  ctl=torch.zeros(12, dtype=torch.float32, device=dev),
                   seam_host=torch.zeros(4, dtype=torch.float32).pin_memory(),
+                  replay_host=torch.zeros(2, dtype=torch.float32).pin_memory(),
                   ctl_host=torch.zeros(8, dtype=torch.float32).pin_memory())
         ws["seam"], ws["status"] = ws["ctl"][0:6], ws["ctl"][8:12].view(torch.int32)
         widths = [H]
@@ -239,11 +271,11 @@ class A2CEngine:
             ev = self.V["valrnn.caption_embedding.weight"].shape[1]
             widths.append(ev)
             ws.update(
-                Xv=f32(lv * n, ev), XPv=f32(lv * n, 4 * H), hv=f32(s, n, H), saved=f32(tv, 6, H), U=f32(n, 512),
+                Xv=f32(lv * n, ev), XPv=f32(lv * n, 4 * H), hv=f32(s, n, H), U=f32(n, 512),
                 Y=f32(s * n, 512), values=f32(s * n), dvalue=f32(s * n),
                 sync_v=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
-                dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H), dgv=f32(tv, 4 * H),
-                hprev=f32(tv, H), dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev))
+                dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H),
+                dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev))
         if self.R is not None:
             ws.update(
                 XPr=f32(l_cols * n, 3 * H), hr=f32(s, n, H), se=f32(s * n, 512), ve=f32(n, 512), rewards=f32(s * n),
@@ -252,23 +284,45 @@ class A2CEngine:
         # 5 of an activation gradient
         scratch = max(16 * 4 * H * H, 8 * (self.vocab or 0) * H, 5 * l_cols * n * max(widths))
         ws["scratch_main"], ws["scratch_side"] = f32(scratch), f32(scratch)
-        k = n if self.per_sample else self._segments_for(tv)
+        k = n if self.per_sample else self._segments_for(tv, tv)
         if k:
             ws["work_v"] = f32(hip.chain_seg_workspace_floats(k))
             ws["work_r"] = f32(hip.chain_seg_workspace_floats(k))
+            if self.collapse and s > 1:   # the replay check's rows: one per call past the first
+                ws["work_cv"] = f32(hip.chain_seg_workspace_floats(s))
+                ws["work_cr"] = f32(hip.chain_seg_workspace_floats(s))
         ws["segments"] = k
+        if s == 1 or not self.collapse:
+            self._chain_capacity(ws, tv, 0)
         self._ws[key] = ws
         return ws
 
-    def _segments_for(self, positions):
-        """Number of segments for a chain of `positions` steps; 0 = use the exact kernels."""
-        if self.chain_mode == "exact" or (self.chain_mode == "auto" and positions < 4096):
+    def _chain_capacity(self, ws, positions_v, positions_r):
+        """Per-position buffers of the chains (the value chain's kept activations and gate gradients, the
+        reward chain's kept activations when the replay check needs them), sized for the chain that is
+        actually walked and grown when more calls have to be walked in full."""
+        dev = self.device
+        if self.V is not None and positions_v > ws["cap_v"]:
+            ws["saved"] = ws["dgv"] = None
+            ws["saved"] = torch.empty(positions_v, 6, H, dtype=torch.float32, device=dev)
+            ws["dgv"] = torch.empty(positions_v, 4 * H, dtype=torch.float32, device=dev)
+            ws["cap_v"] = positions_v
+        if self.R is not None and positions_r > ws["cap_r"]:
+            ws["saved_r"] = None
+            ws["saved_r"] = torch.empty(positions_r, 5, H, dtype=torch.float32, device=dev)
+            ws["cap_r"] = positions_r
+
+    def _segments_for(self, positions, full_positions=None):
+        """Number of segments for a chain of `positions` steps; 0 = use the exact kernels (decided on the
+        length the chain has when every call is walked in full)."""
+        full_positions = positions if full_positions is None else full_positions
+        if self.chain_mode == "exact" or (self.chain_mode == "auto" and full_positions < 4096):
             return 0
         if self.segments:
             return int(self.segments)
         # a step costs about the same for 32 segments as for 512 (fixed per-step time dominates until the
         # device is full), so short chains are cut finer: fewer, fuller steps
-        return max(32, min(512, positions // 16 // 32 * 32))
+        return max(32, min(self.max_segments, positions // 16 // 32 * 32))
 
     def _plans(self, ws):
         if self.per_sample:
@@ -276,6 +330,36 @@ class A2CEngine:
         k = ws["segments"]
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
+
+    def _full_calls(self, n, p0, s, warmups):
+        """How many calls the chains walk in full: the fewest for which every replay left out is at least
+        as long as twice the warm-ups in use (a seam passes after `warmup` steps, so a state is forgotten
+        within that many), as the floor MIN_REPLAY and as what failed replay checks have asked for."""
+        if not self.collapse or s < 2:
+            return s
+        need = max([self.MIN_REPLAY, self._replay_need] + [2 * w for w in warmups])
+        for fc in range(1, s):
+            if (p0 + fc - 1) * n >= need:
+                # not worth a different geometry unless it removes a good part of the chain
+                return fc if hip.chain_positions(n, p0, s, fc) * 4 <= hip.chain_positions(n, p0, s) * 3 else s
+        return s
+
+    def _choose(self, ws, n, p0, s, fv, fr, bi):
+        """(full_calls, value plan, reward plan, backward plan) for the ladder positions fv, fr, bi."""
+        if self.per_sample:
+            return s, ("rows",), ("rows",), ("rows",)
+        last = len(self.warmups)
+        if not ws["segments"]:
+            return s, ("exact",), ("exact",), ("exact",)
+        if fv >= last:   # a value chain that no warm-up reproduced forward is not tried segmented backward
+            bi = last
+        idx = [i for i in (fv, fr, bi) if i < last]
+        fc = s if len(idx) < 3 else self._full_calls(n, p0, s, [self.warmups[i] for i in idx])
+        k = self._segments_for(hip.chain_positions(n, p0, s, fc), ws["tv"])
+        if fc < s and not self.segments:
+            k = min(k, self.COLLAPSED_MAX_SEGMENTS)
+        plan = lambda i: ("segmented", k, self.warmups[i]) if i < last else ("exact",)
+        return fc, plan(fv), plan(fr), plan(bi)
 
     @staticmethod
     def _next_plan(plans, attempt, checks):
@@ -297,6 +381,11 @@ class A2CEngine:
                 return idx
         return len(plans) - 1
 
+    def _next_rung(self, attempt, checks):
+        """_next_plan on the warm-up ladder alone (index len(warmups) = the exact kernels)."""
+        plans = [("segmented", 0, w) for w in self.warmups] + [("exact",)]
+        return self._next_plan(plans, attempt, checks)
+
     def _mark(self, label):
         if self.trace is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -309,15 +398,23 @@ class A2CEngine:
         after the other; which streams collide depends on what else the process has created (an RCCL
         communicator brings several), so candidates are tried until one overlaps."""
         if self._side is None:
-            main = torch.cuda.current_stream()
-            for attempt in range(8):
-                cand = torch.cuda.Stream(device=self.device)
-                if self._side is None:
-                    self._side = cand
-                if _runs_beside(main, cand):
-                    self._side = cand
-                    break
+            self._side = self._stream_beside([torch.cuda.current_stream()])
         return self._side
+
+    def _check_stream(self):
+        """A third stream, beside both the current one and the side stream (the replay check)."""
+        if self._check is None:
+            self._check = self._stream_beside([torch.cuda.current_stream(), self._side_stream()])
+        return self._check
+
+    def _stream_beside(self, others):
+        first = None
+        for attempt in range(8):
+            cand = torch.cuda.Stream(device=self.device)
+            first = first or cand
+            if all(_runs_beside(o, cand) for o in others):
+                return cand
+        return first
 
     def _rollout(self, ws, features, n, p0, s, uniforms, mode):
         """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
@@ -404,8 +501,7 @@ class A2CEngine:
                 hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], n, n, ws["values"])
                 hip.mse_loss(ws["values"], targets, ws["scalars"][0:1], ws["dvalue"])
                 self._value_head_backward(ws, features, n, 1)
-                hip.chain_hprev(ws["saved"], ws["tv"], ws["hprev"])
-            self._value_chain_backward(ws, n, p0, 1, main, main, pb, None)
+            self._value_chain_backward(ws, n, p0, 1, 1, main, main, pb, None)
             seg_v, seg_b = pv[0] == "segmented", pb[0] == "segmented"
             if not (seg_v or seg_b):
                 break
@@ -546,7 +642,6 @@ class A2CEngine:
         assert features.shape == (n, self.F) and features.dtype == torch.float32 and features.is_contiguous()
         ws = self._buffers(n, p0, s)
         P, V, R = self.P, self.V, self.R
-        t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
         tokT = ws["tokT"]
         if mode == hip.FORCED:
             tokT.copy_(forced_tokens.t())
@@ -572,84 +667,127 @@ class A2CEngine:
         self._rollout(ws, features, n, p0, s, uniforms, mode)
         self._mark("rollout_done")
         main.wait_event(ev_feat)
-        plans = self._plans(ws)
-        last = len(plans) - 1
+        last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
+        status_host = None
         # ---- chains forward + loss + backward, enqueued in one go; the forward seam errors come back
         # through pinned memory as soon as the chains are done, so the host knows whether the attempt
-        # stands while the device is still busy with the backward pass.  A rejected forward seam redoes
-        # everything after the rollout; a rejected backward seam (below) only the value chain's BPTT.
+        # stands while the device is still busy with the backward pass.  A rejected forward seam or replay
+        # check redoes everything after the rollout; a rejected backward seam only the value chain's BPTT,
+        # unless its longer warm-up also asks for more calls in full.
         while True:
-            pv, pr = plans[fv], plans[fr]
-            if pv[0] == "exact":   # a value chain that no warm-up reproduced forward is not tried segmented backward
+            fc, pv, pr, pb = self._choose(ws, n, p0, s, fv, fr, bi)
+            if pv[0] == "exact":
                 bi = last
-            pb = plans[bi]
-            ev_seam = self._chains_forward_loss(ws, features, n, p0, s, backward, main, side, pv, pr)
+            ev_seam, ev_replay, replay_steps = self._chains_forward_loss(ws, features, n, p0, s, fc, backward, main, side,
+                                                                         pv, pr)
             if with_bwd:
-                self._backward(ws, features, n, p0, s, main, side, pb)
+                self._backward(ws, features, n, p0, s, fc, main, side, pb)
             self._mark("backward_done")
             seg_v, seg_r = pv[0] == "segmented", pr[0] == "segmented"
-            if not (seg_v or seg_r):
-                break
-            ev_seam.synchronize()
-            seam = ws["seam_host"].tolist()
-            checks_v = [(seam[0], self.SEAM_TOL_FWD)] if seg_v else []
-            checks_r = [(seam[2], self.SEAM_TOL_FWD)] if seg_r else []
-            ok_v, ok_r = (all(e <= t for e, t in c) for c in (checks_v, checks_r))
-            if ok_v and ok_r:
+            if seg_v or seg_r:
+                ev_seam.synchronize()
+                seam = ws["seam_host"].tolist()
+                checks_v = [(seam[0], self.SEAM_TOL_FWD)] if seg_v else []
+                checks_r = [(seam[2], self.SEAM_TOL_FWD)] if seg_r else []
+                ok_v, ok_r = (all(e <= t for e, t in c) for c in (checks_v, checks_r))
+                if not (ok_v and ok_r):
+                    self.fallbacks += 1
+                    if not ok_v:
+                        fv = self._next_rung(fv, checks_v)
+                        self._ladder_fv.rejected(fv)
+                    if not ok_r:
+                        fr = self._next_rung(fr, checks_r)
+                        self._ladder_fr.rejected(fr)
+                    continue
+            if ev_replay is not None:
+                # the replays that were left out: did they come back to the state they started from?
+                ev_replay.synchronize()
+                rep = ws["replay_host"].tolist()
+                self.last_replay = (fc, replay_steps, rep[0], rep[1])
+                if not all(e <= self.REPLAY_TOL for e in rep):
+                    self.fallbacks += 1
+                    self._replay_rejected(n, p0, fc)
+                    continue
+            else:
+                self.last_replay = (fc, 0, 0.0, 0.0)
+            if seg_v or seg_r:
                 self._ladder_fv.accepted(fv, checks_v, last)
                 self._ladder_fr.accepted(fr, checks_r, last)
-                break
-            self.fallbacks += 1
-            if not ok_v:
-                fv = self._next_plan(plans, fv, checks_v)
-                self._ladder_fv.rejected(fv)
-            if not ok_r:
-                fr = self._next_plan(plans, fr, checks_r)
-                self._ladder_fr.rejected(fr)
-        self.last_seam = ws["seam_host"].tolist()[:4] + [0.0, 0.0]
-        if with_bwd and self.on_policy_grads is not None:
-            # the forward pass stands, so the policy gradients being computed now are final
-            self.on_policy_grads(self._ev_policy)
+            self.last_seam = ws["seam_host"].tolist()[:4] + [0.0, 0.0]
+            if with_bwd and self.on_policy_grads is not None and self._ev_policy is not None:
+                # the forward pass stands, so the policy gradients being computed now are final
+                self.on_policy_grads(self._ev_policy)
+                self._ev_policy = None
+            # ---- the backward seam
+            restart = False
+            while with_bwd and pb[0] == "segmented":
+                # one read-back for the backward seam and the status words (the step's one host sync)
+                ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
+                ev_ctl = torch.cuda.Event()
+                ev_ctl.record(main)
+                ev_ctl.synchronize()
+                seam_b = ws["ctl_host"][0:2].tolist()
+                status_host = ws["ctl_host"][4:8].view(torch.int32).tolist()
+                self.last_seam[4:6] = seam_b
+                checks_b = [(seam_b[0] / seam_b[1] if seam_b[1] > 0 else 0.0, self.SEAM_TOL_BWD)]
+                if all(e <= t for e, t in checks_b):
+                    self._ladder_bwd.accepted(bi, checks_b, last)
+                    break
+                self.fallbacks += 1
+                bi = self._next_rung(bi, checks_b)
+                self._ladder_bwd.rejected(bi)
+                if self._choose(ws, n, p0, s, fv, fr, bi)[0] != fc:
+                    restart = True     # the longer warm-up reaches further than the replays left out are long
+                    break
+                pb = self._choose(ws, n, p0, s, fv, fr, bi)[3]
+                self._value_chain_backward(ws, n, p0, s, fc, main, side, pb, None)
+                self._mark("backward_done")
+            if restart:
+                continue
+            break
+        self._replay_accepted()
         # the tensors handed back are final now; their copies queue behind the backward pass
         out = (tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                ws["rewards"].view(s, n).t().contiguous())
-        status_host = None
-        while with_bwd and pb[0] == "segmented":
-            # one read-back for the backward seam and the status words (the step's one host sync)
-            ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
-            ev_ctl = torch.cuda.Event()
-            ev_ctl.record(main)
-            ev_ctl.synchronize()
-            seam_b = ws["ctl_host"][0:2].tolist()
-            status_host = ws["ctl_host"][4:8].view(torch.int32).tolist()
-            self.last_seam[4:6] = seam_b
-            checks_b = [(seam_b[0] / seam_b[1] if seam_b[1] > 0 else 0.0, self.SEAM_TOL_BWD)]
-            if all(e <= t for e, t in checks_b):
-                self._ladder_bwd.accepted(bi, checks_b, last)
-                break
-            self.fallbacks += 1
-            bi = self._next_plan(plans, bi, checks_b)
-            self._ladder_bwd.rejected(bi)
-            pb = plans[bi]
-            self._value_chain_backward(ws, n, p0, s, main, side, pb, None)
-            self._mark("backward_done")
         return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
-                             (pv, pb), pr, status_host)
+                             (pv, pb), pr, status_host, full_calls=fc)
 
-    def _chains_forward_loss(self, ws, features, n, p0, s, backward, main, side, plan, plan_r):
+    def _replay_rejected(self, n, p0, fc):
+        """A replay that was left out did not come back to its start state within the steps checked: ask
+        for replays twice as long (so more calls are walked in full), and do not come back down for a while."""
+        self._replay_need = 2 * max(self.MIN_REPLAY, (p0 + fc - 1) * n)
+        self._replay_cool, self._replay_penalty = self._replay_penalty, min(2 * self._replay_penalty, 1024)
+
+    def _replay_accepted(self):
+        """After a while without a rejection, try shorter replays again (half the length at a time)."""
+        if self._replay_cool > 0:
+            self._replay_cool -= 1
+        elif self._replay_need > 0:
+            self._replay_need = self._replay_need // 2 if self._replay_need // 2 > self.MIN_REPLAY else 0
+            self._replay_cool = 8
+
+    def _chains_forward_loss(self, ws, features, n, p0, s, fc, backward, main, side, plan, plan_r):
         """The two forward chains, the heads and the loss.  plan / plan_r: how the value / reward chain
-        runs.  Returns an event after which ws["seam_host"][:4] holds the forward seam errors."""
+        runs; fc: calls walked in full (fc < s: the later calls' replays are left out, and the check that
+        this is right is started on a stream of its own).  Returns (an event after which ws["seam_host"][:4]
+        holds the forward seam errors, an event after which ws["replay_host"] holds the replay check's two
+        errors or None, the steps that check walks)."""
         P, V, R = self.P, self.V, self.R
-        t_steps, l_cols, lv, tv = p0 - 1 + s, p0 + s, p0 + s - 1, ws["tv"]
+        l_cols, lv = p0 + s, p0 + s - 1
+        tv, tr = hip.chain_positions(n, p0, s, fc), hip.chain_positions(n, p0 + 1, s, fc)
+        collapsed = fc < s
+        self._chain_capacity(ws, tv, tr if collapsed else 0)
         tok_flat = ws["tokT"].view(-1)
         seg, seg_r, rows = plan[0] == "segmented", plan_r[0] == "segmented", plan[0] == "rows"
+        keep = backward or collapsed      # the value chain's activations: for the BPTT, and for the replay check
 
         # ---- 2. the two forward chains: one persistent launch for both when the device can hold it,
         # else the reward GRU chain on the side stream beside the value LSTM chain on the main stream
         # (per-row chains: always one call for both, persistent or a launch per step)
         pair = rows or (seg and seg_r and self.persistent and hip.chain_pair_supported(plan[1]))
+        assert pair or not collapsed or (seg and seg_r), "replays are only left out on the segmented kernels"
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
@@ -661,11 +799,14 @@ class A2CEngine:
                 ev_xpr.record(side)
             elif seg_r:
                 hip.gru_chain_fwd_seg(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
-                                      plan_r[1], plan_r[2], ws["hr"], ws["work_r"], ws["seam"][2:4])
+                                      plan_r[1], plan_r[2], ws["hr"], ws["work_r"], ws["seam"][2:4], full_calls=fc,
+                                      saved=ws["saved_r"] if collapsed else None)
             else:
                 hip.gru_chain_fwd(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                   ws["hr"], ws["sync_r"], ws["status"][1:2])
             if not pair:
+                ev_gru = torch.cuda.Event()
+                ev_gru.record(side)
                 self._reward_head(ws, features, n, s, side, visual_done=True)
                 ev_rew = torch.cuda.Event()
                 ev_rew.record(side)
@@ -682,8 +823,9 @@ class A2CEngine:
         elif pair:
             hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
                                    R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
-                                   ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
-                                   ws["seam"][0:2], ws["seam"][2:4], warmup_r=plan_r[2])
+                                   ws["saved"] if keep else None, ws["hr"], ws["work_v"], ws["work_r"],
+                                   ws["seam"][0:2], ws["seam"][2:4], warmup_r=plan_r[2], full_calls=fc,
+                                   saved_r=ws["saved_r"] if collapsed else None)
         ev_seam = None
         if pair:
             ev_seam = self._seam_to_host(ws, main)
@@ -696,10 +838,31 @@ class A2CEngine:
                 ev_rew.record(side)
         elif seg:
             hip.lstm_chain_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, plan[1], plan[2], ws["hv"],
-                                   ws["saved"] if backward else None, ws["work_v"], ws["seam"][0:2])
+                                   ws["saved"] if keep else None, ws["work_v"], ws["seam"][0:2], full_calls=fc)
         else:
             hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, ws["hv"],
                                ws["saved"] if backward else None, ws["sync_v"], ws["status"][0:1])
+        ev_replay, replay_steps = None, 0
+        if collapsed:
+            # beside everything that follows, on a stream of its own: the first steps of every replay that was
+            # left out, from the state the chain had there (twice the longest warm-up in use: a state is
+            # forgotten within one warm-up, or the seams would not have passed)
+            replay_steps = min((p0 + fc - 1) * n, max(self.MIN_REPLAY, 2 * plan[2], 2 * plan_r[2]))
+            ev_chains = torch.cuda.Event()
+            ev_chains.record(main)
+            check = self._check_stream() if self.concurrent else main
+            with torch.cuda.stream(check):
+                check.wait_event(ev_chains)
+                if not pair:
+                    check.wait_event(ev_gru)
+                hip.chain_pair_replay_check(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["XPr"],
+                                            R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], ws["saved_r"],
+                                            n, p0, p0 + 1, s, fc, replay_steps, ws["work_cv"], ws["work_cr"],
+                                            ws["ctl"][6:8])
+                ws["replay_host"].copy_(ws["ctl"][6:8], non_blocking=True)
+                ev_replay = torch.cuda.Event()
+                ev_replay.record(check)
+                self._mark("check:replay_done")
         w1 = V["linear1.weight"]
         hip.gemm(ws["hv"].view(s * n, H), w1[:, self.F:], ws["Y"])
         hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], s * n, n, ws["values"])
@@ -712,7 +875,7 @@ class A2CEngine:
         hip.a2c_loss(ws["values"], ws["rewards"], ws["logp"].view(-1), ws["scalars"],
                      ws["dvalue"] if backward else None, ws["dlogp"] if backward else None)
         self._mark("loss_done")
-        return ev_seam
+        return ev_seam, ev_replay, replay_steps
 
     @staticmethod
     def _seam_to_host(ws, stream):
@@ -731,17 +894,13 @@ class A2CEngine:
         self._mark("side:reward_done")
 
     # ------------------------------------------------------------------ gradients
-    def _backward(self, ws, features, n, p0, s, main, side, plan):
-        P, V = self.P, self.V
-        gP, gV = self.gP, self.gV
-        t_steps, lv, tv = p0 - 1 + s, p0 + s - 1, ws["tv"]
-        tok_flat = ws["tokT"].view(-1)
+    def _backward(self, ws, features, n, p0, s, fc, main, side, plan):
         ev_loss = torch.cuda.Event()
         ev_loss.record(main)
 
         # ---- value network: head, then the chain's BPTT (main stream)
         self._value_head_backward(ws, features, n, s)
-        self._value_chain_backward(ws, n, p0, s, main, side, plan, ev_loss, features)
+        self._value_chain_backward(ws, n, p0, s, fc, main, side, plan, ev_loss, features)
 
     def _value_head_backward(self, ws, features, n, s):
         """Backward of the two linear layers of the value head (models.py:175-178) from ws["dvalue"]:
@@ -761,37 +920,35 @@ class A2CEngine:
         hip.colsum(dY, gV["linear1.bias"])
         hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
 
-    def _value_chain_backward(self, ws, n, p0, s, main, side, plan, ev_loss, features=None):
+    def _value_chain_backward(self, ws, n, p0, s, fc, main, side, plan, ev_loss, features=None):
         """The value chain's BPTT and everything that consumes it.  With ev_loss the side stream also
         runs the policy network's BPTT beside the chain (first attempt of a step); without, only the
         chain's part is redone (after a rejected seam check)."""
         V, gV = self.V, self.gV
-        lv, tv = p0 + s - 1, ws["tv"]
+        lv, tv = p0 + s - 1, hip.chain_positions(n, p0, s, fc)
         tok_flat = ws["tokT"].view(-1)
-        hprev_stride = n if plan[0] == "rows" else 1
+        saved, dgv = ws["saved"][:tv], ws["dgv"][:tv]
         if plan[0] == "rows":
-            hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
+            hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
                                     ws["work_v"], ws["status"][2:3],
                                     persistent=self.persistent and hip.chain_pair_supported(n))
         elif plan[0] == "segmented":
-            hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, plan[1], plan[2],
-                                   ws["dgv"], ws["work_v"], ws["seam"][4:6],
+            hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
+                                   dgv, ws["work_v"], ws["seam"][4:6], full_calls=fc,
                                    persistent=self.persistent and hip.chain_pair_supported(plan[1]))
         else:
-            hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["d_emit"], n, p0, s, ws["dgv"],
+            assert fc == s
+            hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
                                ws["sync_v"], ws["status"][2:3])
 
         self._mark("value_chain_bwd_done")
         ev_chain = torch.cuda.Event()
         ev_chain.record(main)
-        # ---- side stream: the shifted h stream (needs only forward results), the policy network's BPTT
-        # beside the value chain, then the value network's input-side gradients once the chain is done
+        # ---- side stream: the policy network's BPTT beside the value chain, then the value network's
+        # input-side gradients once the chain is done
         with torch.cuda.stream(side):
             if ev_loss is not None:
                 side.wait_event(ev_loss)
-                hip.chain_hprev(ws["saved"], tv, ws["hprev"], stride=hprev_stride)
-                ev_hprev = torch.cuda.Event()
-                ev_hprev.record(side)
                 self._mark("side:policy_bwd_start")
                 self._policy_backward(ws, features, n, p0, s)
                 self._mark("side:policy_bwd_done")
@@ -799,24 +956,33 @@ class A2CEngine:
                 self._ev_policy.record(side)
             side.wait_event(ev_chain)
             ss = ws["scratch_side"]
-            hip.chain_fold_calls(ws["dgv"], n, p0, s, 4 * H, ws["dGsum"])
-            hip.gemm_auto(ws["dGsum"], ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
-            hip.colsum(ws["dGsum"], gV["valrnn.lstm.bias_ih_l0"])
+            if fc == 1 and p0 == 1 and s > 1:
+                dgsum = dgv          # every column occurs once in the chain: nothing to sum over calls
+            else:
+                dgsum = ws["dGsum"]
+                hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
+            hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
+            hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"])
             gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
             g_emb = gV.get("valrnn.caption_embedding.weight")
             if g_emb is not None:
-                hip.gemm_auto(ws["dGsum"], V["valrnn.lstm.weight_ih_l0"], ws["dXv"], ss, b_kmajor=True)
+                hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], ss, b_kmajor=True)
                 g_emb.zero_()
                 hip.scatter_add_rows(g_emb, tok_flat, 1, lv * n, ws["dXv"])
             self._mark("side:value_input_grads_done")
             ev_side = torch.cuda.Event()
             ev_side.record(side)
 
-        # ---- main stream: the recurrent weight gradient, sum over ~10^5 positions of dgates (x) h_prev
-        if ev_loss is not None:
-            main.wait_event(ev_hprev)
-        hip.gemm_auto(ws["dgv"], ws["hprev"], gV["valrnn.lstm.weight_hh_l0"], ws["scratch_main"], a_kmajor=True,
-                      b_kmajor=True)
+        # ---- main stream: the recurrent weight gradient, sum over the positions of dgates (x) h_prev.  The
+        # previous position's h is read in place from the kept activations (slot 5 of the position before,
+        # a strided view); the chain's first position(s) had h_prev = 0 and drop out of the sum.
+        back = n if plan[0] == "rows" else 1
+        if tv > back:
+            h_prev = saved.view(tv, 6 * H)[:tv - back, 5 * H:]
+            hip.gemm_auto(dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], ws["scratch_main"], a_kmajor=True,
+                          b_kmajor=True)
+        else:
+            gV["valrnn.lstm.weight_hh_l0"].zero_()
         self._mark("value_wgrads_done")
         main.wait_event(ev_side)
 

@@ -25,21 +25,22 @@ SIGNATURES = {
                                      c_int, c_int, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
-    "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_lstm_chain_fwd_seg_static": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 6),
+    "icrl_lstm_chain_fwd_seg_static": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 5),
     "icrl_masked_nll": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_mse_loss": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "icrl_topk_rows": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_chain_pair_supported": (c_int, [c_int]),
-    "icrl_lstm_chain_fwd_seg_persist": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_gru_chain_fwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 7 + [c_vp] * 8),
+    "icrl_lstm_chain_fwd_seg_persist": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 6),
+    "icrl_gru_chain_fwd_seg_persist": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 5),
+    "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 4),
+    "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp] * 9),
+    "icrl_chain_pair_replay_check": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
     "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_gru_chain_fwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_gru_chain_fwd_seg": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 5),
     "icrl_gru_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_lstm_chain_bwd_seg": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_lstm_chain_bwd_seg": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 4),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
@@ -57,7 +58,7 @@ SIGNATURES = {
     "icrl_gru_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_vse_loss": (c_int, [c_vp, c_int, ctypes.c_float, c_vp, c_vp, c_vp, c_vp]),
     "icrl_lstm_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "icrl_chain_fold_calls": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "icrl_chain_fold_calls": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "icrl_chain_hprev": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_vp]),
     "icrl_value_head_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "icrl_cosine_reward": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
@@ -66,7 +67,7 @@ SIGNATURES = {
 }
 
 SAMPLE, GREEDY, FORCED = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -78,8 +79,11 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, kind, work, nbytes=0.0):
-        self.kind, self.work, self.nbytes = kind, work, nbytes
+    """steps: launches / in-launch steps a segmented chain call really executes (warm-up included);
+    flops: the MFMA work of those steps, when it is not gates * 2 * segments * 512 * 512 per step."""
+
+    def __init__(self, kind, work, nbytes=0.0, steps=0, flops=0.0):
+        self.kind, self.work, self.nbytes, self.steps, self.flops = kind, work, nbytes, steps, flops
 
     def __enter__(self):
         if PROFILE is not None:
@@ -90,11 +94,19 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record(torch.cuda.current_stream())
-            PROFILE.append((self.kind, self.work, self.e0, self.e1, self.nbytes))
+            PROFILE.append((self.kind, self.work, self.e0, self.e1, self.nbytes, self.steps, self.flops))
 
 
-def chain_positions(n, p0, n_calls):
-    return n * sum(p0 + s for s in range(n_calls))
+def chain_positions(n, p0, n_calls, full_calls=0):
+    """Positions of a chain whose first `full_calls` calls (0: all) are walked in full and whose later calls
+    contribute their last column only."""
+    fc = n_calls if not full_calls else full_calls
+    return n * (sum(p0 + s for s in range(fc)) + n_calls - fc)
+
+
+def _seg_steps(n, p0, n_calls, full_calls, segments, warmup):
+    """Steps a segmented chain call walks: warm-up + positions per segment."""
+    return warmup + -(-chain_positions(n, p0, n_calls, full_calls) // segments)
 
 
 class HipExtensionMissing(RuntimeError):
@@ -141,10 +153,11 @@ def _check(rc, what):
 
 
 def _chain_shapes(who, n, p0, n_calls, gates, xproj=None, h_emit=None, saved=None, slots=0, d_emit=None, dgates=(),
-                  work=None, segments=None, w_hh=None):
+                  work=None, segments=None, w_hh=None, full_calls=0):
     """Host-side check that every buffer of a chain call is as large as the kernels' indexing assumes (a
     kernel that runs past a buffer faults the GPU, it does not raise)."""
-    cols, positions = p0 + n_calls - 1, chain_positions(n, p0, n_calls)
+    cols, positions = p0 + n_calls - 1, chain_positions(n, p0, n_calls, full_calls)
+    assert 0 <= full_calls <= n_calls, "%s: full_calls must be in [0, n_calls]" % who
     def need(t, count, name):
         if t is not None and not isinstance(t, int):
             assert t.numel() >= count, "%s: %s has %d elements, the chain needs %d" % (who, name, t.numel(), count)
@@ -318,9 +331,11 @@ def lstm_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates, sync_ws, status)
     _check(rc, "icrl_lstm_chain_bwd")
 
 
-def chain_fold_calls(dgates, n, p0, n_calls, width, out):
-    _check(load().icrl_chain_fold_calls(_ptr(_f32c(dgates)), n, p0, n_calls, width, _ptr(_f32c(out)), _stream()),
-           "icrl_chain_fold_calls")
+def chain_fold_calls(dgates, n, p0, n_calls, width, out, full_calls=0):
+    assert dgates.numel() >= chain_positions(n, p0, n_calls, full_calls) * width
+    assert out.numel() >= (p0 + n_calls - 1) * n * width
+    _check(load().icrl_chain_fold_calls(_ptr(_f32c(dgates)), n, p0, n_calls, full_calls, width, _ptr(_f32c(out)),
+                                        _stream()), "icrl_chain_fold_calls")
 
 
 def chain_hprev(saved, positions, h_prev, gru=False, stride=1):
@@ -428,38 +443,39 @@ def chain_seg_workspace_floats(segments):
 
 
 def lstm_chain_fwd_seg(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, work, seam_err, state_in=None,
-                       persistent=False):
+                       persistent=False, full_calls=0):
     """state_in: {h, c} (1024 floats) the chain starts from; None = zeros.  persistent: all steps in one
     launch (needs chain_pair_supported(segments))."""
     _chain_shapes("lstm_chain_fwd_seg", n, p0, n_calls, 4, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=6,
-                  work=work, segments=segments)
+                  work=work, segments=segments, full_calls=full_calls)
     fn = load().icrl_lstm_chain_fwd_seg_persist if persistent else load().icrl_lstm_chain_fwd_seg
-    with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
-        rc = fn(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, segments, warmup,
+    with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls, full_calls), steps=_seg_steps(n, p0, n_calls, full_calls, segments, warmup)):
+        rc = fn(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, full_calls, segments, warmup,
                                             _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(_f32c(work)),
                                             _ptr(seam_err), _stream())
     _check(rc, "icrl_lstm_chain_fwd_seg")
 
 
-def lstm_chain_fwd_seg_static(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, seam_err, state_in=None):
+def lstm_chain_fwd_seg_static(xproj, w_hh, n, p0, n_calls, segments, warmup, h_emit, saved, seam_err, state_in=None,
+                              full_calls=0):
     """lstm_chain_fwd_seg on the library's static workspace (at most 128 segments): no allocation, no
     workspace argument.  Calls on one GPU share that workspace and must not overlap."""
     _chain_shapes("lstm_chain_fwd_seg_static", n, p0, n_calls, 4, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved,
-                  slots=6)
-    rc = load().icrl_lstm_chain_fwd_seg_static(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, segments, warmup,
+                  slots=6, full_calls=full_calls)
+    rc = load().icrl_lstm_chain_fwd_seg_static(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, full_calls, segments, warmup,
                                                _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(seam_err),
                                                _stream())
     _check(rc, "icrl_lstm_chain_fwd_seg_static")
 
 
 def gru_chain_fwd_seg(xproj, w_hh, b_hh, n, p0, n_calls, segments, warmup, h_emit, work, seam_err, saved=None,
-                      persistent=False):
+                      persistent=False, full_calls=0):
     """persistent: all steps in one launch (needs chain_pair_supported(segments))."""
     _chain_shapes("gru_chain_fwd_seg", n, p0, n_calls, 3, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=5,
-                  work=work, segments=segments)
+                  work=work, segments=segments, full_calls=full_calls)
     fn = load().icrl_gru_chain_fwd_seg_persist if persistent else load().icrl_gru_chain_fwd_seg
-    with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
-        rc = fn(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
+    with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls, full_calls), steps=_seg_steps(n, p0, n_calls, full_calls, segments, warmup)):
+        rc = fn(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls, full_calls,
                                            segments, warmup, _ptr(_f32c(h_emit)), _ptr(saved), _ptr(_f32c(work)),
                                            _ptr(seam_err), _stream())
     _check(rc, "icrl_gru_chain_fwd_seg")
@@ -478,21 +494,47 @@ def chain_pair_supported(segments):
 
 
 def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, segments, warmup, h_emit_v,
-                       saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r, warmup_r=None):
+                       saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r, warmup_r=None, full_calls=0,
+                       saved_r=None):
     """Value LSTM chain and reward GRU chain, every step, in one persistent launch (warmup_r: the
     reward chain's own warm-up length; default: the value chain's)."""
     _chain_shapes("chain_pair_fwd_seg (value)", n, p0_v, n_calls, 4, xproj=xproj_v, w_hh=w_hh_v, h_emit=h_emit_v,
-                  saved=saved_v, slots=6, work=work_v, segments=segments)
+                  saved=saved_v, slots=6, work=work_v, segments=segments, full_calls=full_calls)
     _chain_shapes("chain_pair_fwd_seg (reward)", n, p0_r, n_calls, 3, xproj=xproj_r, w_hh=w_hh_r, h_emit=h_emit_r,
-                  work=work_r, segments=segments)
-    with _Timed("chain_pair_fwd", chain_positions(n, p0_v, n_calls) + chain_positions(n, p0_r, n_calls)):
+                  saved=saved_r, slots=5, work=work_r, segments=segments, full_calls=full_calls)
+    warmup_r = warmup if warmup_r is None else warmup_r
+    with _Timed("chain_pair_fwd", chain_positions(n, p0_v, n_calls, full_calls) + chain_positions(n, p0_r, n_calls, full_calls),
+                steps=max(_seg_steps(n, p0_v, n_calls, full_calls, segments, warmup),
+                          _seg_steps(n, p0_r, n_calls, full_calls, segments, warmup_r)),
+                flops=2.0 * segments * 512 * 512 * (4 * _seg_steps(n, p0_v, n_calls, full_calls, segments, warmup) +
+                                                    3 * _seg_steps(n, p0_r, n_calls, full_calls, segments, warmup_r))):
         rc = load().icrl_chain_pair_fwd_seg(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
-                                            _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls,
-                                            segments, warmup, warmup if warmup_r is None else warmup_r,
+                                            _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls, full_calls,
+                                            segments, warmup, warmup_r,
                                             _ptr(_f32c(h_emit_v)), _ptr(saved_v),
-                                            _ptr(_f32c(h_emit_r)), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
+                                            _ptr(_f32c(h_emit_r)), _ptr(saved_r), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
                                             _ptr(seam_err_v), _ptr(seam_err_r), _stream())
     _check(rc, "icrl_chain_pair_fwd_seg")
+
+
+def chain_pair_replay_check(xproj_v, w_hh_v, saved_v, xproj_r, w_hh_r, b_hh_r, saved_r, n, p0_v, p0_r, n_calls, full_calls,
+                            steps, work_v, work_r, err):
+    """Runs, for every call whose replay the chains left out (full_calls < n_calls), the first `steps` positions
+    of that replay from the state the chain had before the call, and writes to err[0:2] how far the value LSTM's /
+    reward GRU's state then is from the state the last fully walked call had there."""
+    rows = n_calls - full_calls
+    assert 1 <= full_calls < n_calls and 1 <= steps <= n * (min(p0_v, p0_r) + full_calls - 1)
+    assert saved_v.numel() >= chain_positions(n, p0_v, n_calls, full_calls) * 6 * 512
+    assert saved_r.numel() >= chain_positions(n, p0_r, n_calls, full_calls) * 5 * 512
+    assert xproj_v.numel() >= steps * 4 * 512 and xproj_r.numel() >= steps * 3 * 512
+    assert work_v.numel() >= chain_seg_workspace_floats(rows) and work_r.numel() >= chain_seg_workspace_floats(rows)
+    assert err.numel() >= 2
+    with _Timed("replay_check", rows * steps, steps=steps + 1):
+        rc = load().icrl_chain_pair_replay_check(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(saved_v)),
+                                                 _ptr(_f32c(xproj_r)), _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)),
+                                                 _ptr(_f32c(saved_r)), n, p0_v, p0_r, n_calls, full_calls, steps,
+                                                 _ptr(_f32c(work_v)), _ptr(_f32c(work_r)), _ptr(_f32c(err)), _stream())
+    _check(rc, "icrl_chain_pair_replay_check")
 
 
 def chain_pair_fwd_rows(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, h_emit_v, saved_v, h_emit_r,
@@ -523,13 +565,14 @@ def lstm_chain_bwd_rows(w_hh, saved, d_emit, n, p0, n_calls, dgates, work, statu
     _check(rc, "icrl_lstm_chain_bwd_rows")
 
 
-def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False):
+def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False,
+                       full_calls=0):
     _chain_shapes("lstm_chain_bwd_seg", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit,
-                  dgates=(dgates,), work=work, segments=segments)
+                  dgates=(dgates,), work=work, segments=segments, full_calls=full_calls)
     fn = load().icrl_lstm_chain_bwd_seg_persist if persistent else load().icrl_lstm_chain_bwd_seg
-    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
+    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls, full_calls), steps=_seg_steps(n, p0, n_calls, full_calls, segments, warmup)):
         rc = fn(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
-                                            n_calls, segments, warmup, _ptr(_f32c(dgates)), _ptr(_f32c(work)),
+                                            n_calls, full_calls, segments, warmup, _ptr(_f32c(dgates)), _ptr(_f32c(work)),
                                             _ptr(seam_err), _stream())
     _check(rc, "icrl_lstm_chain_bwd_seg")
 

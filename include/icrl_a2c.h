@@ -31,7 +31,7 @@ typedef void* icrl_stream_t;
 #define ICRL_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define ICRL_ERR_TIMEOUT (-3) /* a chain kernel gave up waiting for a peer workgroup */
 
-#define ICRL_ABI_VERSION 1
+#define ICRL_ABI_VERSION 2
 
 int icrl_abi_version(void);
 const char* icrl_last_error(void);
@@ -190,9 +190,21 @@ int icrl_gru_chain_bwd(const float* w_hh, const float* saved, const float* d_emi
  * outputs and layouts as icrl_lstm_chain_fwd / icrl_gru_chain_fwd / icrl_lstm_chain_bwd
  * (zero initial state; icrl_lstm_chain_fwd_seg also takes state_in = {h, c}, 2*512 floats, or NULL: the
  * state the chain starts from, as ValueNetworkRNN.hidden_cell carries it from call to call,
- * models.py:133-134); work = icrl_chain_seg_workspace_floats(segments) floats. */
+ * models.py:133-134); work = icrl_chain_seg_workspace_floats(segments) floats.
+ *
+ * full_calls (0 = n_calls = every call in full).  Call s of the reference walks caption columns
+ * 0 .. p0+s-1 (models.py:168-169, 254-255), so call s+1 begins by REPLAYING every input of call s, from
+ * the state call s ended in, before it reads its one new column.  A recurrence that forgets ends that
+ * replay in the state it started from, and the replay can then be left out: with full_calls = f the chain
+ * is calls 0 .. f-1 in full followed by the LAST column only of calls f .. n_calls-1, i.e.
+ * N * (f*p0 + f(f-1)/2 + n_calls - f) positions instead of N * (n_calls*p0 + n_calls(n_calls-1)/2);
+ * `saved` and `dgates` are indexed by the positions of that shorter chain, h_emit / d_emit are unchanged.
+ * The hidden outputs agree with the full chain's, and the gate gradients with the full chain's summed
+ * over the calls that contain a column (icrl_chain_fold_calls), to the accuracy with which the replays
+ * return to their start state - which the caller must check with icrl_chain_pair_replay_check, and the
+ * backward pass by requiring its accepted warm-up to be shorter than the shortest replay left out. */
 int64_t icrl_chain_seg_workspace_floats(int segments);
-int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
                             int segments, int warmup, float* h_emit, float* saved, const float* state_in,
                             float* work, float* seam_err, icrl_stream_t stream);
 /* icrl_lstm_chain_fwd_seg for callers that cannot allocate or carry a workspace (code under HIP graph
@@ -203,13 +215,13 @@ int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0
  * (its first call on a device looks the array's address up once).  Every call on one GPU shares that
  * array: calls that overlap on one GPU (two streams, two host threads) race; calls in stream order are
  * safe, whatever their sizes. */
-int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
                                    int segments, int warmup, float* h_emit, float* saved,
                                    const float* state_in, float* seam_err, icrl_stream_t stream);
 /* saved (may be NULL): the GRU chain's activations {r, z, n, hn, h}, 5*512 floats per position, as
  * icrl_gru_chain_fwd keeps them for icrl_gru_chain_bwd. */
 int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                           int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                           int n_calls, int full_calls, int segments, int warmup, float* h_emit, float* saved,
                            float* work, float* seam_err, icrl_stream_t stream);
 /* icrl_gru_chain_bwd (the BPTT through RewardNetworkRNN's recurrence, trainers.py:288-300) evaluated
  * segment-parallel: same inputs, outputs and layouts; seam_err as for icrl_lstm_chain_bwd_seg
@@ -219,7 +231,7 @@ int icrl_gru_chain_bwd_seg(const float* w_hh, const float* saved, const float* d
                            int n_calls, int segments, int warmup, float* dgates_x, float* dgates_h,
                            float* work, float* seam_err, icrl_stream_t stream);
 int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
-                            int n_calls, int segments, int warmup, float* dgates, float* work,
+                            int n_calls, int full_calls, int segments, int warmup, float* dgates, float* work,
                             float* seam_err, icrl_stream_t stream);
 
 /* Both forward chains of one minibatch (value LSTM: models.py:133, 140-143; reward GRU:
@@ -236,9 +248,24 @@ int icrl_lstm_chain_bwd_seg(const float* w_hh, const float* saved, const float* 
 int icrl_chain_pair_supported(int segments);
 int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
                             const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
-                            int n_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
-                            float* saved_v, float* h_emit_r, float* work_v, float* work_r,
+                            int n_calls, int full_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
+                            float* saved_v, float* h_emit_r, float* saved_r, float* work_v, float* work_r,
                             float* seam_err_v, float* seam_err_r, icrl_stream_t stream);
+
+/* The check that goes with full_calls < n_calls (no counterpart in the reference, which always replays):
+ * for every call s >= full_calls, run the first `steps` positions of the replay that was left out, from the
+ * state the chain had at the end of call s-1 (taken from saved_v / saved_r, the activations the forward
+ * launch kept: LSTM {i,f,g,o,c,h}, GRU {r,z,n,hn,h} per position of the shortened chain), all calls side by
+ * side in one persistent launch, and compare the state reached with the state the last fully walked call
+ * had after the same inputs.  err[0] (value LSTM, h and c) and err[1] (reward GRU, h) receive
+ * max |a-b| / max(1,|b|); +inf if the launch gave up waiting.  At rounding level the replays may be left
+ * out; otherwise rerun the chains with a larger full_calls.  steps <= N * (p0 + full_calls - 1), the
+ * shortest replay left out.  work_v / work_r: icrl_chain_seg_workspace_floats(n_calls - full_calls)
+ * floats each, not shared with a launch that may run at the same time. */
+int icrl_chain_pair_replay_check(const float* xproj_v, const float* w_hh_v, const float* saved_v,
+                                 const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
+                                 const float* saved_r, int N, int p0_v, int p0_r, int n_calls, int full_calls,
+                                 int steps, float* work_v, float* work_r, float* err, icrl_stream_t stream);
 
 /* One forward chain alone in the same persistent launch (the look-ahead decoder's value calls,
  * trainers.py:73-105, and the pre-training loops, trainers.py:125-199, run one chain at a time):
@@ -246,23 +273,24 @@ int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const flo
  * arguments and the same results bit for bit, without a kernel boundary per step; state_in needs
  * warmup >= 1.  Needs icrl_chain_pair_supported(segments); a
  * hand-off time-out sets seam_err[0] = +inf. */
-int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls,
+int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
                                     int segments, int warmup, float* h_emit, float* saved,
                                     const float* state_in, float* work, float* seam_err,
                                     icrl_stream_t stream);
 int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,
-                                   int n_calls, int segments, int warmup, float* h_emit, float* saved,
+                                   int n_calls, int full_calls, int segments, int warmup, float* h_emit, float* saved,
                                    float* work, float* seam_err, icrl_stream_t stream);
 
 /* icrl_lstm_chain_bwd_seg (the BPTT of models.py:140-143's recurrence) as ONE persistent
  * launch: same arguments, same results bit for bit, no kernel boundary per step.  Needs
  * icrl_chain_pair_supported(segments); a hand-off time-out sets seam_err[0] = +inf. */
 int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const float* d_emit, int N,
-                                    int p0, int n_calls, int segments, int warmup, float* dgates,
+                                    int p0, int n_calls, int full_calls, int segments, int warmup, float* dgates,
                                     float* work, float* seam_err, icrl_stream_t stream);
 
-/* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] */
-int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int width, float* out,
+/* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] (positions of the
+ * chain with `full_calls` calls in full; with full_calls = 1 and p0 = 1 every column occurs once) */
+int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int full_calls, int width, float* out,
                           icrl_stream_t stream);
 /* h_prev[pos, :] = h of position pos-stride (zeros for pos < stride), taken from `saved` (gru = 0:
  * the LSTM chain's 6 slots per position; 1: the GRU chain's 5).  stride 1: the batch-1 chains;

@@ -37,7 +37,13 @@ def sample_row(p_row, u):
     return orc.inverse_cdf_sample(p_row, u)
 
 
-def lstm_chain(xproj, w_hh, n, p0, n_calls, want_grad_of=None):
+def call_columns(p0, s, full_calls):
+    """Columns call s contributes to a chain: all of 0 .. p0+s-1, or (calls past the first `full_calls`, whose
+    replay of the earlier columns is left out) the last one only.  full_calls = 0: every call in full."""
+    return range(p0 + s) if (not full_calls or s < full_calls) else range(p0 + s - 1, p0 + s)
+
+
+def lstm_chain(xproj, w_hh, n, p0, n_calls, want_grad_of=None, full_calls=0):
     """Flattened batch-1 LSTM chain (models.py:133 with seq = N, batch = 1).
 
     xproj [(cols*n), 4H] already holds W_ih x + b_ih + b_hh.  Returns h_emit
@@ -51,7 +57,7 @@ def lstm_chain(xproj, w_hh, n, p0, n_calls, want_grad_of=None):
     emit, saved, pres = [], [], []
     for s in range(n_calls):
         outs = None
-        for t in range(p0 + s):
+        for t in call_columns(p0, s, full_calls):
             outs = []
             for i in range(n):
                 pre = xp[t * n + i][None] + h @ whh_t
@@ -75,7 +81,7 @@ def lstm_chain(xproj, w_hh, n, p0, n_calls, want_grad_of=None):
     return h_emit.detach().numpy(), saved.numpy(), dg.numpy()
 
 
-def gru_chain(xproj, w_hh, b_hh, n, p0, n_calls):
+def gru_chain(xproj, w_hh, b_hh, n, p0, n_calls, full_calls=0):
     """Flattened batch-1 GRU chain (models.py:226); call s covers p0+s+1 columns.
     xproj [(cols*n), 3H] holds W_ih x + b_ih; gate order r,z,n."""
     xp = torch.tensor(np.asarray(xproj), dtype=torch.float64)
@@ -85,7 +91,7 @@ def gru_chain(xproj, w_hh, b_hh, n, p0, n_calls):
     emit = []
     for s in range(n_calls):
         outs = None
-        for t in range(p0 + s + 1):
+        for t in call_columns(p0 + 1, s, full_calls):
             outs = []
             for i in range(n):
                 h = orc._gru_step(xp[t * n + i][None], h, whh_t, bhh)
