@@ -331,13 +331,20 @@ class A2CEngine:
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
 
-    def _full_calls(self, n, p0, s, warmups):
+    def _replay_steps(self, w_fwd):
+        """Steps of a left-out replay that the check walks: a quarter more than the longest forward warm-up
+        in use (the seams say that a zero state is forgotten within one warm-up).  The check measures, so
+        any length is safe; a short one only risks asking for more calls in full than needed."""
+        return max(self.MIN_REPLAY, w_fwd + w_fwd // 4)
+
+    def _full_calls(self, n, p0, s, w_fwd, w_bwd):
         """How many calls the chains walk in full: the fewest for which every replay left out is at least
-        as long as twice the warm-ups in use (a seam passes after `warmup` steps, so a state is forgotten
-        within that many), as the floor MIN_REPLAY and as what failed replay checks have asked for."""
+        as long as the steps the replay check walks, as the backward warm-up (a gradient that a seam check
+        shows to be gone after `warmup` steps does not reach through a replay that long), as the floor
+        MIN_REPLAY and as what failed replay checks have asked for."""
         if not self.collapse or s < 2:
             return s
-        need = max([self.MIN_REPLAY, self._replay_need] + [2 * w for w in warmups])
+        need = max(self._replay_need, self._replay_steps(w_fwd), w_bwd)
         for fc in range(1, s):
             if (p0 + fc - 1) * n >= need:
                 # not worth a different geometry unless it removes a good part of the chain
@@ -354,7 +361,7 @@ class A2CEngine:
         if fv >= last:   # a value chain that no warm-up reproduced forward is not tried segmented backward
             bi = last
         idx = [i for i in (fv, fr, bi) if i < last]
-        fc = s if len(idx) < 3 else self._full_calls(n, p0, s, [self.warmups[i] for i in idx])
+        fc = s if len(idx) < 3 else self._full_calls(n, p0, s, max(self.warmups[fv], self.warmups[fr]), self.warmups[bi])
         k = self._segments_for(hip.chain_positions(n, p0, s, fc), ws["tv"])
         if fc < s and not self.segments:
             k = min(k, self.COLLAPSED_MAX_SEGMENTS)
@@ -845,9 +852,8 @@ class A2CEngine:
         ev_replay, replay_steps = None, 0
         if collapsed:
             # beside everything that follows, on a stream of its own: the first steps of every replay that was
-            # left out, from the state the chain had there (twice the longest warm-up in use: a state is
-            # forgotten within one warm-up, or the seams would not have passed)
-            replay_steps = min((p0 + fc - 1) * n, max(self.MIN_REPLAY, 2 * plan[2], 2 * plan_r[2]))
+            # left out, from the state the chain had there
+            replay_steps = min((p0 + fc - 1) * n, self._replay_steps(max(plan[2], plan_r[2])))
             ev_chains = torch.cuda.Event()
             ev_chains.record(main)
             check = self._check_stream() if self.concurrent else main
