@@ -9,11 +9,22 @@ gradient all-reduce across ranks (N > 1), Adam.  Workload: the batch-512 configu
 headline metric is quoted on - batch 512 per GPU, 2048-d features, vocab 10k, caption length T = 20, float32 arithmetic.
 Inputs (features, start tokens, uniforms) are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.
+
+Beside the K timed steps the line carries
+  * `soak`: a further run of minibatches on the same networks (they keep training, and the value LSTM's
+    memory - hence the chains' warm-up - grows with it): mean / p95 step time, the plans it ended on and
+    how many minibatches had to be redone;
+  * `roofline`: the f32 MFMA GEMM launches of one timed step (HIP events around every launch, on the stream
+    it is launched on), FLOPs / time against the f32 MFMA peak;
+  * `chains`: the recurrent-chain launches of the same step with the steps they walked, their MFMA work as
+    executed (warm-up included) and as the reference's chains would need;
+  * `cpu_baseline`: the reference-shaped float32 CPU port timed on this host (rank 0, N = 1 only).
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,14 +36,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 PKG = "image-captioning-through-rl_amd"
 
-F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense, MI355X
+F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, dense, MI355X
 
 
-def build_networks(syn, models, optim, vocab, fdim, seed, dev):
+def build_networks(syn, models, optim, vocab, fdim, seed, dev, value_forget_bias=0.0):
     w2i = syn.make_word_to_idx(vocab)
     nets = (models.PolicyNetwork(w2i, input_dim=fdim), models.ValueNetwork(w2i, feature_dim=fdim),
             models.RewardNetwork(w2i, feature_dim=fdim))
     params = [syn.make_params(k, vocab, fdim, seed) for k in ("policy", "value", "reward")]
+    if value_forget_bias:
+        params[1]["valrnn.lstm.bias_ih_l0"][512:1024] += value_forget_bias
     for net, p in zip(nets, params):
         net.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
         net.to(dev)
@@ -43,20 +56,63 @@ def build_networks(syn, models, optim, vocab, fdim, seed, dev):
     return a2c, rew, flat, params
 
 
-def cpu_baseline(syn, params, vocab, caplen, fdim, sample_batch):
-    """The reference-shaped float32 CPU port (oracle/cpu_port.py), one minibatch of
-    `sample_batch` rows of the same workload, on this host's cores."""
+def host_cores():
+    """(threads torch uses, CPUs this process may run on, physical cores among them)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = set()
+    try:
+        for cpu in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            with open(base + "physical_package_id") as f, open(base + "core_id") as g:
+                cores.add((f.read().strip(), g.read().strip()))
+    except OSError:
+        cores = set()
+    return torch.get_num_threads(), len(allowed), len(cores) or None
+
+
+def cpu_baseline(syn, params, vocab, caplen, fdim, sample_batch, repeats):
+    """The reference-shaped float32 CPU port (oracle/cpu_port.py) on this host's cores: one untimed
+    minibatch, then the median of `repeats` timed ones, `sample_batch` rows of the same workload each."""
     from oracle import cpu_port
     nets = cpu_port.PortNets(params[0], params[1], params[2], vocab, fdim)
     opt = cpu_port.make_optimizer(nets)
     feats, caps = syn.make_minibatch(sample_batch, vocab, caplen, fdim, 0)
     np.random.seed(0)
-    t0 = time.perf_counter()
-    cpu_port.a2c_minibatch(nets, opt, feats, caps)
-    dt = time.perf_counter() - t0
-    return {"value": sample_batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 A2C minibatch of %d rows (vocab %d, T=%d, %d-d features), float32 torch-CPU, %.1f s"
-                      % (sample_batch, vocab, caplen, fdim, dt)}
+    times = []
+    for i in range(repeats + 1):
+        t0 = time.perf_counter()
+        cpu_port.a2c_minibatch(nets, opt, feats, caps)
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    threads, allowed, physical = host_cores()
+    return {"value": sample_batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "cpus_allowed": allowed, "physical_cores_allowed": physical,
+            "sample": "median of %d A2C minibatches (after one untimed) of %d rows (vocab %d, T=%d, %d-d features), "
+                      "float32 torch-CPU on %d threads, %.1f s each" % (repeats, sample_batch, vocab, caplen, fdim,
+                                                                        threads, dt)}
+
+
+def git_sha():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
+def load_profile(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def plans_of(res, engine):
+    fwd, bwd = res.chain_plan
+    return {"forward": list(fwd), "reward_forward": list(res.reward_plan), "backward": list(bwd),
+            "full_calls": res.full_calls, "replay_check": list(engine.last_replay) if engine.last_replay else None}
 
 
 def main():
@@ -68,11 +124,22 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--caplen", type=int, default=20)
     ap.add_argument("--fdim", type=int, default=2048)
-    ap.add_argument("--cpu-sample-batch", type=int, default=512)
+    ap.add_argument("--soak", type=int, default=150, help="minibatches of the steady-state run after the timed steps (0: none)")
+    ap.add_argument("--cpu-sample-batch", type=int, default=256)
+    ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo: the ranks' collectives go through host memory (rehearsal of the N > 1 path on one GPU)")
+    ap.add_argument("--policy-dtype", default="f32", choices=("f32", "bf16"),
+                    help="bf16: the policy network's products on the bf16 matrix instruction (NOT the headline "
+                         "workload's arithmetic: reported under its own workload name and dtype)")
+    ap.add_argument("--value-forget-bias", type=float, default=0.0,
+                    help="added to the value LSTM's forget-gate bias: a recurrence with a longer memory (stress case, "
+                         "reported under its own workload name)")
     ap.add_argument("--chain-semantics", default="batch", choices=("batch", "per_sample"),
                     help="per_sample: every image owns its value / reward recurrent state (NOT the headline "
                          "workload: a different computation, reported under its own workload name)")
+    ap.add_argument("--no-collapse", action="store_true", help="walk every call of the chains in full")
     args = ap.parse_args()
 
     syn = importlib.import_module(PKG + ".synthetic")
@@ -82,20 +149,24 @@ def main():
     trainers = importlib.import_module(PKG + ".trainers")
     ddp = importlib.import_module(PKG + ".dist")
 
-    rank, world, local = ddp.init_from_env("nccl")
+    rank, world, local = ddp.init_from_env(args.backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local = local % max(1, torch.cuda.device_count())   # more ranks than GPUs (a rehearsal): they share
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     n, vocab, caplen, fdim = args.batch, args.vocab, args.caplen, args.fdim
     steps_per_rollout = caplen - 1
 
-    a2c, rew, flat, params = build_networks(syn, models, optim, vocab, fdim, 0, dev)
+    a2c, rew, flat, params = build_networks(syn, models, optim, vocab, fdim, 0, dev, args.value_forget_bias)
     opt = optim.FusedAdam(flat, lr=1e-4)
-    engine = trainers.build_engine(a2c, rew, chain_semantics=args.chain_semantics)
+    engine_opts = dict(chain_semantics=args.chain_semantics, collapse_replays=not args.no_collapse)
+    if args.policy_dtype != "f32":
+        engine_opts["policy_dtype"] = args.policy_dtype
+    engine = trainers.build_engine(a2c, rew, **engine_opts)
     feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, rank)  # a different shard per rank
     feats_d = torch.from_numpy(feats).to(dev)
     prefix_d = torch.from_numpy(caps[:, :1]).to(dev)
-    total_steps = args.warmup + args.steps
+    total_steps = args.warmup + args.steps + args.soak
     uniforms = torch.from_numpy(
         np.random.RandomState(1000 + rank).random_sample((total_steps, steps_per_rollout * n))).to(dev)
 
@@ -116,120 +187,158 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     # per-launch HIP events (on the launching streams) bracket the launches of the FIRST timed step only:
-    # every step issues the same launches, and the ~120 event records of a step cost ~0.5 ms of it
+    # a step's ~120 event records cost ~0.5 ms of it.  The plans that step ran with are kept beside them.
     hip.PROFILE = []
-    profiled_steps = 1
     prof = hip.PROFILE
+    fallbacks_before = engine.fallbacks
+    profiled_plans, profiled_clean = None, True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == profiled_steps:
+        if i == 1:
             hip.PROFILE = None
         res = one_step(args.warmup + i)
+        if i == 0:
+            profiled_plans = plans_of(res, engine)
+            profiled_clean = engine.fallbacks == fallbacks_before   # no redone attempt among the recorded launches
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     elapsed = ddp.max_over_ranks(time.perf_counter() - t0, dev)
     hip.PROFILE = None
+    timed_fallbacks = engine.fallbacks - fallbacks_before
+    final_plans = plans_of(res, engine)
+    last_loss = float(res.scalars[0])
 
-    # per-kernel accounting from the HIP events recorded on each launch's own stream
-    acc = {}
-    for kind, work, e0, e1, nbytes, _steps, _flops in prof:
+    # ---- steady state: the networks keep training, the value LSTM's memory (and with it the warm-up) moves
+    soak = None
+    if args.soak > 0:
+        times, before = [], engine.fallbacks
+        for i in range(args.soak):
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            res_s = one_step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - s0)
+        worst = ddp.max_over_ranks(float(np.mean(times)), dev)
+        soak = {"minibatches": args.soak, "after_minibatches": args.warmup + args.steps,
+                "ms_per_step_mean": 1e3 * worst, "ms_per_step_p95": 1e3 * float(np.percentile(times, 95)),
+                "ms_per_step_max": 1e3 * float(np.max(times)), "images_per_s": world * n / worst,
+                "redone_minibatches": engine.fallbacks - before, "final_plans": plans_of(res_s, engine),
+                "note": "each minibatch synchronised and timed on the host; the same networks keep training"}
+
+    # ---- per-kernel accounting of the profiled step from the HIP events recorded on each launch's own stream
+    acc, chain_steps, chain_flops = {}, {}, {}
+    for kind, work, e0, e1, nbytes, steps, flops in prof:
         a = acc.setdefault(kind, [0.0, 0.0, 0, 0.0])
         a[0] += work
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
         a[3] += nbytes
-    gemm_flops, gemm_s, gemm_launches, gemm_bytes = acc["gemm"]
-    # HBM traffic of the same launches from PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE
-    # doubled as gfx950 needs), measured offline on this workload and committed under profiles/
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f)["gemm_f32_kernel"]
-        traffic = pmc["fetch_bytes_per_launch"] + pmc["write_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    mfma_util = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_mfma.json")) as f:
-            mfma_util = {k: v["mfma_utilisation"] for k, v in json.load(f).items() if k != "_note"}
-    except (OSError, KeyError, ValueError, TypeError):
-        pass
+        chain_steps[kind] = chain_steps.get(kind, 0) + steps
+        chain_flops[kind] = chain_flops.get(kind, 0.0) + flops
+    gemm_kinds = [k for k in acc if k.startswith("gemm")]
+    gemm_flops, gemm_s, gemm_launches, gemm_bytes = (sum(acc[k][j] for k in gemm_kinds) for j in range(4))
+    peak = F32_MFMA_PEAK_TFLOPS
     achieved = gemm_flops / gemm_s / 1e12
-    chains = {k: {"dependent_steps_per_minibatch": int(v[0] / profiled_steps), "us_per_step": 1e6 * v[1] / v[0],
-                  "ms_per_minibatch": 1e3 * v[1] / profiled_steps}
-              for k, v in acc.items() if k != "gemm"}
+    pmc_t, pmc_m = load_profile("pmc_traffic.json"), load_profile("pmc_mfma.json")
+    traffic = None
+    if pmc_t and "gemm_f32_kernel" in pmc_t:
+        traffic = pmc_t["gemm_f32_kernel"]["fetch_bytes_per_launch"] + pmc_t["gemm_f32_kernel"]["write_bytes_per_launch"]
+    mfma_util = {k: v["mfma_utilisation"] for k, v in pmc_m.items() if isinstance(v, dict) and "mfma_utilisation" in v} \
+        if pmc_m else None
+
+    # the chains: steps each launch walked, MFMA work executed and the work the reference's chains hold
+    gates = {"lstm_chain_fwd": 4, "gru_chain_fwd": 3, "lstm_chain_bwd": 4}
+    ref_positions = {"lstm_chain_fwd": hip.chain_positions(n, 1, steps_per_rollout),
+                     "gru_chain_fwd": hip.chain_positions(n, 2, steps_per_rollout),
+                     "lstm_chain_bwd": hip.chain_positions(n, 1, steps_per_rollout)}
+    per_position = 2.0 * 512 * 512
+    ref_flops = {k: gates[k] * ref_positions[k] * per_position for k in gates}
+    ref_flops["chain_pair_fwd"] = ref_flops["lstm_chain_fwd"] + ref_flops["gru_chain_fwd"]
+    chains, executed_chain_flops = {}, 0.0
+    segs = profiled_plans["forward"][1] if profiled_plans and profiled_plans["forward"][0] == "segmented" else None
+    for kind, (work, secs, launches, _) in acc.items():
+        if kind.startswith("gemm"):
+            continue
+        entry = {"launches": launches, "positions_walked": int(work), "steps": chain_steps[kind],
+                 "ms": 1e3 * secs, "us_per_step": 1e6 * secs / max(1, chain_steps[kind])}
+        executed = None
+        if chain_flops[kind] > 0:
+            executed = chain_flops[kind]
+        elif kind in gates and segs:
+            executed = chain_steps[kind] * segs * gates[kind] * per_position
+        if executed is not None:
+            executed_chain_flops += executed
+            tf = executed / secs / 1e12
+            entry.update({"gflop_executed": executed / 1e9, "achieved_tflops": tf, "frac_of_f32_mfma_peak": tf / peak})
+        if kind in ref_flops:
+            entry["gflop_reference_chain"] = ref_flops[kind] / 1e9
+        chains[kind] = entry
+
     # minimal-algorithm FLOPs of the policy path per image (fwd x3 for fwd+bwd)
     e_dim = h_dim = 512
     fwd = 2 * fdim * h_dim + steps_per_rollout * (2 * (e_dim + h_dim) * 4 * h_dim + 2 * h_dim * vocab)
     policy_flops_per_image = 3 * fwd
     value = world * n * args.steps / elapsed
-    # MFMA work the segment-parallel chain kernels executed (warm-up steps included): per launch one
-    # [segments, 512] x [512, G*512] product; the chain events above time those launches
-    seg_flops = 0.0
-    plan_fwd, plan_bwd = res.chain_plan
-    plan_rew = res.reward_plan
-    flops_of = {}
-    for kind, gates, p0, plan in (("lstm_chain_fwd", 4, 1, plan_fwd), ("gru_chain_fwd", 3, 2, plan_rew),
-                                  ("lstm_chain_bwd", 4, 1, plan_bwd)):
-        if plan[0] == "segmented":
-            _, segs, warm = plan
-            positions = hip.chain_positions(n, p0, steps_per_rollout)
-            launches = warm + (positions + segs - 1) // segs
-            flops_of[kind] = launches * 2.0 * segs * 512 * gates * 512
-            seg_flops += flops_of[kind]
-    if "lstm_chain_fwd" in flops_of and "gru_chain_fwd" in flops_of:
-        flops_of["chain_pair_fwd"] = flops_of["lstm_chain_fwd"] + flops_of["gru_chain_fwd"]
-    for kind, entry in chains.items():
-        if kind in flops_of:   # the segment-parallel kernels are f32 MFMA kernels: price them like the GEMM
-            tf = flops_of[kind] / (entry["ms_per_minibatch"] * 1e-3) / 1e12
-            entry.update({"gflop_per_minibatch": flops_of[kind] / 1e9, "achieved_tflops": tf,
-                          "frac_of_f32_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS})
     step_s = elapsed / args.steps
 
     if rank == 0:
+        variant = []
+        if args.chain_semantics != "batch":
+            variant.append("NOT the metric's workload: per-image recurrent state")
+        if args.value_forget_bias:
+            variant.append("NOT the metric's workload: value LSTM forget bias +%g (long-memory stress case)" % args.value_forget_bias)
+        if args.policy_dtype != "f32":
+            variant.append("NOT the metric's arithmetic: policy network products in %s" % args.policy_dtype)
+        if (n, fdim, vocab, caplen) != (512, 2048, 10000, 20):
+            variant.append("NOT the metric's size")
         out = {
             "metric": "images/sec per A2C train step (batch 512, T=20, vocab 10k)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "A2C minibatch: batch %d per GPU, %d-d features, vocab %d, T=%d "
-                                   "(%s%s)" % (n, fdim, vocab, caplen,
-                                               "the metric's batch-512 configuration" if args.chain_semantics == "batch"
-                                               else "NOT the metric's workload: per-image recurrent state",
-                                               ", data-parallel over the GPUs" if world > 1 else ""),
-                       "global_batch": world * n, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "ms_per_step": 1e3 * step_s, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.policy_dtype, "data": "synthetic",
+            "config": {"workload": "A2C minibatch: batch %d per GPU, %d-d features, vocab %d, T=%d (%s%s)"
+                                   % (n, fdim, vocab, caplen,
+                                      "; ".join(variant) if variant else "the metric's batch-512 configuration",
+                                      ", data-parallel over the GPUs" if world > 1 else ""),
+                       "global_batch": world * n, "parallelism": "dp%d" % world,
+                       "backend": args.backend if world > 1 else None},
+            "soak": soak,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
-                         "algorithmic_bytes_per_launch": gemm_bytes / gemm_launches,
+                         "traffic_profile_git_sha": (pmc_t or {}).get("_git_sha"),
+                         "algorithmic_bytes_per_launch": gemm_bytes / max(1, gemm_launches),
                          "kernel": "gemm_f32_kernel, all launches of a step (policy LSTM/vocab GEMMs fwd+bwd, "
                                    "chain input projections and weight gradients)",
-                         "launches_per_step": gemm_launches // profiled_steps,
-                         "gflop_per_step": gemm_flops / profiled_steps / 1e9,
-                         "ms_per_step_in_kernel": 1e3 * gemm_s / profiled_steps,
-                         "events": "HIP events around every launch of the first of the timed steps",
+                         "launches_per_step": gemm_launches, "gflop_per_step": gemm_flops / 1e9,
+                         "ms_per_step_in_kernel": 1e3 * gemm_s,
+                         "events": "HIP events around every launch of the first of the timed steps, on its own stream",
                          "mfma_utilisation_pmc": mfma_util,
+                         "mfma_profile_git_sha": (pmc_m or {}).get("_git_sha"),
                          "mfma_utilisation_note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch cycles * 1024 SIMDs) per kernel, "
                                                   "kernels run one at a time (profiles/pmc_mfma.json)"},
             "chains": chains,
+            "profiled_step": {"plans": profiled_plans, "no_attempt_redone": profiled_clean,
+                              "note": "the roofline and chain figures are this step's launches, with this step's plans"},
             "mfma_work_of_whole_step": {
-                "gflop_executed_per_step": (gemm_flops / profiled_steps + seg_flops) / 1e9,
-                "achieved_tflops": (gemm_flops / profiled_steps + seg_flops) / step_s / 1e12,
-                "frac_of_f32_mfma_peak": (gemm_flops / profiled_steps + seg_flops) / step_s / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                "note": "all f32 MFMA FLOPs launched in a step (GEMM launches + segment-parallel chain steps, "
-                        "their warm-up included) over the step's wall time"},
+                "gflop_executed_per_step": (gemm_flops + executed_chain_flops) / 1e9,
+                "achieved_tflops": (gemm_flops + executed_chain_flops) / step_s / 1e12,
+                "frac_of_f32_mfma_peak": (gemm_flops + executed_chain_flops) / step_s / 1e12 / peak,
+                "note": "all f32 MFMA FLOPs launched in the profiled step (GEMM launches + segment-parallel chain "
+                        "steps, their warm-up included) over the mean step time"},
             "lstm_gemm_roofline_of_whole_step": {
                 "policy_flops_per_image_fwd_bwd": policy_flops_per_image,
                 "achieved_tflops": policy_flops_per_image * value / world / 1e12,
-                "frac_of_f32_mfma_peak": policy_flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS},
-            "chain_plan": {"forward": list(plan_fwd), "reward_forward": list(plan_rew), "backward": list(plan_bwd)},
-            "seam_check": engine.last_seam,
-            "seam_fallbacks_in_run": engine.fallbacks, "last_loss": float(res.scalars[0]),
+                "frac_of_f32_mfma_peak": policy_flops_per_image * value / world / 1e12 / peak},
+            "chain_plan": final_plans, "seam_check": engine.last_seam,
+            "seam_fallbacks_in_run": timed_fallbacks, "last_loss": last_loss, "git_sha": git_sha(),
         }
-        if world == 1 and not args.no_cpu_baseline and args.chain_semantics == "batch":
-            out["cpu_baseline"] = cpu_baseline(syn, params, vocab, caplen, fdim, args.cpu_sample_batch)
+        if world == 1 and not args.no_cpu_baseline and args.chain_semantics == "batch" and not args.value_forget_bias:
+            out["cpu_baseline"] = cpu_baseline(syn, params, vocab, caplen, fdim, args.cpu_sample_batch, args.cpu_repeats)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+            if soak:
+                out["soak_speedup_vs_cpu_port"] = soak["images_per_s"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -290,7 +290,7 @@ def chain_sync_bytes():
 def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, state_in=None, state_out=None):
     """p0 = caption columns seen by the first call; call s covers p0 + s columns."""
     _chain_shapes("lstm_chain_fwd", n, p0, n_calls, 4, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=6)
-    with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls)):
+    with _Timed("lstm_chain_fwd", chain_positions(n, p0, n_calls), steps=chain_positions(n, p0, n_calls)):
         rc = load().icrl_lstm_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), n, p0, n_calls, _ptr(_f32c(h_emit)),
                                         _ptr(saved), _ptr(state_in), _ptr(state_out), _ptr(sync_ws), _ptr(status),
                                         _stream())
@@ -300,7 +300,7 @@ def lstm_chain_fwd(xproj, w_hh, n, p0, n_calls, h_emit, saved, sync_ws, status, 
 def gru_chain_fwd(xproj, w_hh, b_hh, n, p0, n_calls, h_emit, sync_ws, status, state_in=None, state_out=None,
                   saved=None):
     _chain_shapes("gru_chain_fwd", n, p0, n_calls, 3, xproj=xproj, w_hh=w_hh, h_emit=h_emit, saved=saved, slots=5)
-    with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls)):
+    with _Timed("gru_chain_fwd", chain_positions(n, p0, n_calls), steps=chain_positions(n, p0, n_calls)):
         rc = load().icrl_gru_chain_fwd(_ptr(_f32c(xproj)), _ptr(_f32c(w_hh)), _ptr(_f32c(b_hh)), n, p0, n_calls,
                                        _ptr(_f32c(h_emit)), _ptr(saved), _ptr(state_in), _ptr(state_out),
                                        _ptr(sync_ws), _ptr(status), _stream())
@@ -325,7 +325,7 @@ def vse_loss(s_matrix, beta, row_scratch, loss, d_s=None):
 
 def lstm_chain_bwd(w_hh, saved, d_emit, n, p0, n_calls, dgates, sync_ws, status):
     _chain_shapes("lstm_chain_bwd", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit, dgates=(dgates,))
-    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls)):
+    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls), steps=chain_positions(n, p0, n_calls)):
         rc = load().icrl_lstm_chain_bwd(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls,
                                         _ptr(_f32c(dgates)), _ptr(sync_ws), _ptr(status), _stream())
     _check(rc, "icrl_lstm_chain_bwd")
