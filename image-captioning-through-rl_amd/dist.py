@@ -120,6 +120,49 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_main():
+    """True on the rank that writes checkpoints, result files and logged scalars."""
+    return rank() == 0
+
+
+def agree_min(value):
+    """The smallest `value` (an int) any rank holds: a decision every rank must take alike - skipping a
+    minibatch, say - is taken on this, so that no rank leaves the others waiting in a collective."""
+    if not _active():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def same_permutation(perm):
+    """Rank 0's copy of an index permutation on every rank (the ranks draw it from their own torch
+    generators, which agree only if they were seeded alike)."""
+    if not _active():
+        return perm
+    t = perm.clone()
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0)
+    return t.cpu()
+
+
+def decorrelate_numpy_stream():
+    """Give every rank its own NumPy global stream (the sampling uniforms are drawn from it): one draw from
+    the stream as it stands, then a reseed that depends on the rank.  A no-op for a single process, so a
+    single-process run consumes the stream exactly as the reference does."""
+    if world_size() > 1:
+        import numpy as np
+        base = int(np.random.randint(0, 2 ** 31 - 1))
+        np.random.seed((base + 7919 * rank()) % (2 ** 32))
+
+
 def shard_rows(total_rows, rank=None, world=None):
     """Contiguous, equal row shard [lo, hi) of a global minibatch for this rank."""
     world = world_size() if world is None else world

@@ -1,11 +1,18 @@
 """The reference's A2C entry points (trainers.py) on the HIP path.
 
-Kept: ``GenerateCaptionsGreedy``, ``GetRewards``, ``a2c_training``,
-``a2c_curriculum_training``, ``train_a2c_network`` - same names, argument order and
-meaning, same logged scalar tags, same NumPy / torch RNG consumption (so the same seeds
-give the same minibatch order and the same sampled tokens as the reference).
-Not built here (off the A2C step): the three supervised pre-training loops, the beam
-look-ahead decoder and the evaluation loop (trainers.py:73-105, 125-309, 619-665).
+``GenerateCaptionsGreedy``, ``GetRewards``, ``a2c_training``, ``a2c_curriculum_training``,
+``train_a2c_network``, the three supervised pre-training loops (``train_policy_network``,
+``train_value_network``, ``train_reward_network``), the beam look-ahead decoder
+``GenerateCaptionsWithActorCriticLookAhead`` and the evaluation loop ``test_a2c_network``: same names,
+argument order and meaning, same logged scalar tags, same NumPy / torch RNG consumption (so the same
+seeds give the same minibatch order and the same sampled tokens as the reference).
+
+With more than one process (torch.distributed initialised, one rank per GPU) every loop here is
+data-parallel: each rank takes its own rows of every global minibatch (utilities.sharded_minibatches),
+draws its sampling uniforms from its own NumPy stream, starts from rank 0's parameters, averages the
+flat gradient buffer before every optimizer step, takes the "skip this minibatch" decision of the
+curriculum loop together with the other ranks, and only rank 0 writes checkpoints, result files and
+logged scalars.
 """
 import math
 import os
@@ -37,7 +44,14 @@ class ScalarLog:
         self.records.append((tag, float(value), int(step)))
 
 
+class _NoLog:
+    def add_scalar(self, tag, value, step):
+        pass
+
+
 def make_writer(plot_dir):
+    if not ddp.is_main():   # one rank logs
+        return _NoLog()
     if hasattr(plot_dir, "add_scalar"):  # a writer object may be passed instead of a directory
         return plot_dir
     try:
@@ -225,6 +239,7 @@ def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, s
     writer = make_writer(plot_dir)
     print_green('[Training] Training Advantage Actor-Critic Network')
     engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics)
+    ddp.decorrelate_numpy_stream()
     best_loss = float('inf')
     for epoch in range(epochs):
         for minibatch_id, (captions, features, _) in enumerate(
@@ -252,13 +267,15 @@ def a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, 
     print_green('[Training] Training Advantage Actor-Critic Network')
     print_green(f'[Training] mode set to curriculum training using levels: {curriculum}')
     engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics)
+    ddp.decorrelate_numpy_stream()
     for level in curriculum:
         print_green(f'[Training] Training curriculum level: {level}')
         for epoch in range(epochs):
             for minibatch_id, (captions, features, _) in enumerate(
                     minibatches(train_data, batch_size=batch_size, split='train')):
                 curr_seq_len = caption_length(captions) - level
-                if curr_seq_len >= 1:
+                # every rank or none: a rank that skipped alone would leave the others waiting in the all-reduce
+                if ddp.agree_min(curr_seq_len) >= 1:
                     res = _a2c_minibatch(engine, optimizer, captions, features, curr_seq_len, level).check()
                     loss, _, _, mean_reward, mean_adv = res.scalars[:5].tolist()
                     step = global_minibatch_number(epoch, minibatch_id, batch_size)
@@ -285,9 +302,16 @@ def _ce_weights(captions, steps):
 
 def _save_if_best(loss, best_loss, network, path):
     if loss < best_loss:
-        torch.save(network.state_dict(), path)
+        if ddp.is_main():
+            torch.save(network.state_dict(), path)
         return loss
     return best_loss
+
+
+def _after_checkpoints():
+    """Checkpoints are written by rank 0: the others wait here before anything reads them."""
+    if ddp.world_size() > 1:
+        torch.distributed.barrier()
 
 
 def train_policy_network(train_data, network_paths, plot_dir, bidirectional, epochs=100, batch_size=512):
@@ -298,6 +322,7 @@ def train_policy_network(train_data, network_paths, plot_dir, bidirectional, epo
     policy_network = PolicyNetwork(train_data["word_to_idx"], input_dim=fdim,
                                    pretrained_embeddings=train_data["embeddings"], bidirectional=bidirectional).to(device)
     flat = flatten_module(policy_network)
+    ddp.broadcast_parameters(flat.flat)
     optimizer = FusedAdam(flat, lr=0.001)
     engine = A2CEngine(_params_of(policy_network), None, None, _grads_of(policy_network))
     writer = make_writer(plot_dir)
@@ -315,6 +340,7 @@ def train_policy_network(train_data, network_paths, plot_dir, bidirectional, epo
             writer.add_scalar('Policy Network-loss', loss, global_minibatch_number(epoch, minibatch_id, batch_size))
             ddp.average_gradients(flat.flat_grad)
             optimizer.step()
+    _after_checkpoints()
     return policy_network
 
 
@@ -336,6 +362,7 @@ def train_value_network(train_data, network_paths, plot_dir, bidirectional, epoc
     policy_network.train(False).requires_grad_(False)
     value_network = ValueNetwork(w2i, pretrained_embeddings=emb, bidirectional=bidirectional, feature_dim=fdim).to(device)
     flat = flatten_module(value_network)
+    ddp.broadcast_parameters(flat.flat)
     optimizer = FusedAdam(flat, lr=0.001)
     engine = A2CEngine(None, _params_of(value_network), None, None, _grads_of(value_network))
     writer = make_writer(plot_dir)
@@ -358,6 +385,7 @@ def train_value_network(train_data, network_paths, plot_dir, bidirectional, epoc
             optimizer.step()
             value_network.valrnn.init_hidden()
             reward_network.rewrnn.init_hidden()
+    _after_checkpoints()
     return value_network
 
 
@@ -369,6 +397,7 @@ def train_reward_network(train_data, network_paths, plot_dir, bidirectional, epo
     reward_network = RewardNetwork(train_data["word_to_idx"], pretrained_embeddings=train_data["embeddings"],
                                    bidirectional=bidirectional, feature_dim=fdim).to(device)
     flat = flatten_module(reward_network)
+    ddp.broadcast_parameters(flat.flat)
     optimizer = FusedAdam(flat, lr=0.0001)
     engine = A2CEngine(None, None, _params_of(reward_network), reward_grads=_grads_of(reward_network))
     writer = make_writer(plot_dir)
@@ -387,6 +416,7 @@ def train_reward_network(train_data, network_paths, plot_dir, bidirectional, epo
             ddp.average_gradients(flat.flat_grad)
             optimizer.step()
             reward_network.rewrnn.init_hidden()
+    _after_checkpoints()
     return reward_network
 
 
@@ -465,8 +495,9 @@ def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirecti
         a2c_network = a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir,
                                               save_paths, batch_size, epochs, curriculum,
                                               chain_semantics=chain_semantics)
-    with open(results_save_path, 'a') as f:
-        f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
-        f.write(str(a2c_network))
-        f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
+    if ddp.is_main():
+        with open(results_save_path, 'a') as f:
+            f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
+            f.write(str(a2c_network))
+            f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')
     return a2c_network

@@ -1,13 +1,11 @@
 """The parts of the reference's utilities.py that the A2C training path and the look-ahead test
 loop call: minibatch iteration, caption decoding, checkpoint save / load, logging helpers.  Dataset readers, word
 embedding tooling, metrics and post-processing are not part of this path."""
-import os
-
 import numpy as np
 import torch
 from torch import randperm, save
 
-from .models import AdvantageActorCriticNetwork, PolicyNetwork, ValueNetwork, device
+from .models import device
 
 
 def print_green(text):
@@ -93,11 +91,39 @@ class DeviceFeatureStore:
 
 def minibatches(data, batch_size=100, split='train'):
     """get_coco_minibatches, or the device-resident store when the data dict carries one under
-    'feature_store' (built once by the caller: data['feature_store'] = DeviceFeatureStore(data))."""
+    'feature_store' (built once by the caller: data['feature_store'] = DeviceFeatureStore(data)).
+    With more than one rank every rank gets its own `batch_size` rows of each global minibatch of
+    world * batch_size rows (sharded_minibatches)."""
+    from . import dist as ddp
+    if ddp.world_size() > 1:
+        return sharded_minibatches(data, batch_size, split)
     store = data.get('feature_store') if hasattr(data, 'get') else None
     if store is not None and store.split == split:
         return store.minibatches(batch_size)
     return get_coco_minibatches(data, batch_size=batch_size, split=split)
+
+
+def sharded_minibatches(data, batch_size=100, split='train'):
+    """One shuffled pass over the split for data-parallel training: the permutation is rank 0's (one
+    torch.randperm draw on every rank, as in get_coco_minibatches), it is cut into global minibatches of
+    world * batch_size rows, and rank r takes rows [r * b, (r + 1) * b) of each, b = batch_size (the last,
+    shorter global minibatch is split evenly and its remainder dropped, so that every rank runs the same
+    number of equally sized minibatches: the mean of the ranks' means is then the global mean, and no rank
+    waits for another in a collective).  Yields (captions, features, urls) like get_coco_minibatches."""
+    from . import dist as ddp
+    world, rank = ddp.world_size(), ddp.rank()
+    captions_all = data['%s_captions' % split]
+    total = captions_all.shape[0]
+    permutation = ddp.same_permutation(randperm(total))
+    for i in range(0, total, world * batch_size):
+        chunk = permutation[i: i + world * batch_size]
+        per = min(batch_size, len(chunk) // world)
+        if per == 0:
+            return
+        mask = chunk[rank * per: (rank + 1) * per].numpy()   # an index array keeps a one-row shard two-dimensional
+        image_idxs = data['%s_image_idxs' % split][mask]
+        urls = data.get('%s_urls' % split) if hasattr(data, 'get') else data['%s_urls' % split]
+        yield captions_all[mask], data['%s_features' % split][image_idxs], None if urls is None else urls[image_idxs]
 
 
 def global_minibatch_number(epoch, batch_id, batch_size):
@@ -106,37 +132,10 @@ def global_minibatch_number(epoch, batch_id, batch_size):
 
 
 def save_a2c_model(model, save_paths):
-    """utilities.py:286-296."""
-    if isinstance(save_paths, list):
-        for path in save_paths:
-            save(model.state_dict(), path)
-    elif isinstance(save_paths, str):
-        save(model.state_dict(), save_paths)
-
-
-def load_a2c_models(model_path, train_data, network_paths, bidirectional, feature_dim=512):
-    """utilities.py:299-323: rebuild the three modules and load their state_dicts."""
-    policy_network = PolicyNetwork(train_data["word_to_idx"], input_dim=feature_dim,
-                                   pretrained_embeddings=train_data["embeddings"],
-                                   bidirectional=bidirectional).to(device)
-    policy_network.load_state_dict(torch.load(network_paths["policy_network"], map_location=device), strict=False)
-    value_network = ValueNetwork(train_data["word_to_idx"], pretrained_embeddings=train_data["embeddings"],
-                                 bidirectional=bidirectional, feature_dim=feature_dim).to(device)
-    value_network.load_state_dict(torch.load(network_paths["value_network"], map_location=device), strict=False)
-    a2c_network = AdvantageActorCriticNetwork(value_network, policy_network).to(device)
-    a2c_network.load_state_dict(torch.load(model_path, map_location=device), strict=False)
-    a2c_network.policy_network.train(mode=False)
-    a2c_network.value_network.train(mode=False)
-    return a2c_network
-
-
-def get_filename(base_name, bidirectional, curriculum=None):
-    """utilities.py:326-338."""
-    name, ext = os.path.splitext(base_name)
-    if bidirectional:
-        name += "_bidirectional"
-    if curriculum is not None:
-        if curriculum:
-            name += "_curriculum"
-    name += ext
-    return name
+    """The A2C network's state_dict to one path or to each path of a list (utilities.py:286-296); with
+    several ranks only the first one writes."""
+    from . import dist as ddp
+    if not ddp.is_main():
+        return
+    for path in ([save_paths] if isinstance(save_paths, str) else list(save_paths or [])):
+        save(model.state_dict(), path)
