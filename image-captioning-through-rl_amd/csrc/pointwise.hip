@@ -2,6 +2,8 @@
 // column sums, the batched LSTM cell, value head finish, cosine reward, the
 // advantage / policy-gradient loss, d-logits and Adam.  All are HBM-bound: 16-byte
 // accesses per lane, grid capped at ~2048 workgroups with grid-stride loops.
+#include <algorithm>
+
 #include "icrl_common.h"
 
 namespace {
@@ -45,8 +47,11 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict
 
 // out[n] (+)= sum_r x[r, n]: workgroup (bx, by) sums 64 columns over its slice of the rows (4 waves
 // stride it) and adds its partial to out[] with one float atomic per column.
+// partials != null: the workgroup's partial goes to partials[blockIdx.y][col] instead, and colsum_finish adds
+// the row blocks' partials in a fixed order (same bits on every run, which float atomics do not give).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
-                                                     int cols, int rows_per_block, float* __restrict__ out) {
+                                                     int cols, int rows_per_block, float* __restrict__ out,
+                                                     float* __restrict__ partials) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -59,8 +64,139 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
     part[wave][lane] = s0 + s1;
     __syncthreads();
-    if (wave == 0 && col < cols)
-        atomicAdd(out + col, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    if (wave == 0 && col < cols) {
+        const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (partials) partials[(int64_t)blockIdx.y * cols + col] = v;
+        else atomicAdd(out + col, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish(const float* __restrict__ partials, int row_blocks, int cols,
+                                                     float* __restrict__ out, int accumulate) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < cols) {
+        int b = wave;
+        for (; b + 4 < row_blocks; b += 8) { s0 += partials[(int64_t)b * cols + col]; s1 += partials[(int64_t)(b + 4) * cols + col]; }
+        if (b < row_blocks) s0 += partials[(int64_t)b * cols + col];
+    }
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[col] = accumulate ? out[col] + v : v;
+    }
+}
+
+// ---------------------------------------------------------------- embedding gradient, reproducible
+// grad_table[v, :] = sum over the rows r with idx[r] == v of rows_in[r, :], added in ascending r: the rows are
+// first ordered by token (a counting sort whose every step is exact integer work: per-token counts, their
+// exclusive scan, then each token's rows listed in ascending order), then one workgroup per token sums its
+// rows.  The same bits on every run; tokens nobody used get zeros (the table is overwritten, not added to).
+constexpr int EMB_CHUNK = 4096;   // tokens staged in LDS per pass of the scan over the rows
+constexpr int EMB_SLICES = 8;     // the rows are cut into this many contiguous slices, scanned by different workgroups
+
+// workgroup (x, y): tokens [256x, 256x + 256) against the rows of slice y.  FILL = false: slice_count[y][v] = how
+// many of the slice's rows hold v.  FILL = true: slice_count[y][v] holds where v's rows of this slice start in
+// `order` (emb_offsets put it there); they are listed from there on in ascending order.
+template <bool FILL>
+__global__ __launch_bounds__(256) void emb_rows_of_token(const int64_t* __restrict__ idx, int64_t idx_stride, int rows,
+                                                         int vocab, int* __restrict__ slice_count,
+                                                         int* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) int tok[EMB_CHUNK];
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int per_slice = ((rows + EMB_SLICES - 1) / EMB_SLICES + 15) / 16 * 16;
+    const int row0 = blockIdx.y * per_slice, row1 = min(rows, row0 + per_slice);
+    int* mine = slice_count + (int64_t)blockIdx.y * vocab;
+    int found = 0;
+    int next = (FILL && v < vocab) ? mine[v] : 0;
+    for (int base = row0; base < row1; base += EMB_CHUNK) {
+        const int n = min(EMB_CHUNK, row1 - base);
+        for (int k = threadIdx.x; k < EMB_CHUNK; k += 256)
+            tok[k] = k < n ? (int)idx[(int64_t)(base + k) * idx_stride] : -1;
+        __syncthreads();
+        if (v < vocab) {
+            const int4* t4 = reinterpret_cast<const int4*>(tok);
+            for (int k = 0; k < (n + 15) / 16; ++k) {   // the chunk is padded with -1 up to EMB_CHUNK
+                int4 t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = t4[4 * k + q];   // every lane reads the same address: LDS broadcasts
+                int hits = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hits += (t[q].x == v) + (t[q].y == v) + (t[q].z == v) + (t[q].w == v);
+                if (!FILL) {
+                    found += hits;
+                } else if (hits) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = base + 16 * k + 4 * q;
+                        if (t[q].x == v) order[next++] = r;
+                        if (t[q].y == v) order[next++] = r + 1;
+                        if (t[q].z == v) order[next++] = r + 2;
+                        if (t[q].w == v) order[next++] = r + 3;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!FILL && v < vocab) mine[v] = found;
+}
+
+// count[v] = rows that hold v (all slices), offset[v] = sum of count[0 .. v), and slice_count[y][v] becomes where
+// v's rows of slice y start: offset[v] + the counts of the slices before y  (one workgroup; chunks of 1024 tokens
+// with a running carry)
+__global__ __launch_bounds__(1024) void emb_offsets(int* __restrict__ slice_count, int vocab, int* __restrict__ count,
+                                                    int* __restrict__ offset) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < vocab; base += 1024) {
+        const int v = base + threadIdx.x;
+        int c = 0;
+        if (v < vocab)
+            for (int y = 0; y < EMB_SLICES; ++y) c += slice_count[(int64_t)y * vocab + v];
+        part[threadIdx.x] = c;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan
+            const int add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (v < vocab) {
+            int at = carry + part[threadIdx.x] - c;
+            count[v] = c;
+            offset[v] = at;
+            for (int y = 0; y < EMB_SLICES; ++y) {
+                const int here = slice_count[(int64_t)y * vocab + v];
+                slice_count[(int64_t)y * vocab + v] = at;
+                at += here;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(128) void emb_sum_rows(const float* __restrict__ rows_in, int width, const int* __restrict__ count,
+                                                    const int* __restrict__ offset, const int* __restrict__ order,
+                                                    float* __restrict__ grad) {
+    const int v = blockIdx.x;
+    const int n = count[v], first = offset[v];
+    const int w4 = width >> 2;
+    for (int c = threadIdx.x; c < w4; c += 128) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < n; ++k) {
+            const float4 a = reinterpret_cast<const float4*>(rows_in + (int64_t)order[first + k] * width)[c];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        reinterpret_cast<float4*>(grad + (int64_t)v * width)[c] = s;
+    }
 }
 
 // ---------------------------------------------------------------- batched LSTM cell
@@ -450,18 +586,59 @@ extern "C" int icrl_scatter_add_rows(float* grad_table, int width, const int64_t
     return ICRL_OK;
 }
 
+extern "C" int64_t icrl_colsum_scratch_floats(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int col_blocks = (cols + 63) / 64;
+    int row_blocks = std::max(1, std::min(2048 / col_blocks, (rows + 63) / 64));
+    return (int64_t)row_blocks * cols;
+}
+
 extern "C" int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
-                           icrl_stream_t stream) {
+                           float* scratch, icrl_stream_t stream) {
     ICRL_REQUIRE(x && out && rows > 0 && cols > 0, "icrl_colsum: null pointer or empty shape");
     hipStream_t st = as_stream(stream);
-    if (!accumulate) ICRL_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
     const int col_blocks = (cols + 63) / 64;
-    int row_blocks = 2048 / col_blocks;                   // aim at ~2048 workgroups
-    if (row_blocks > (rows + 63) / 64) row_blocks = (rows + 63) / 64;
-    if (row_blocks < 1) row_blocks = 1;
+    const int row_blocks = std::max(1, std::min(2048 / col_blocks, (rows + 63) / 64));   // aim at ~2048 workgroups
     const int rows_per_block = (rows + row_blocks - 1) / row_blocks;
+    if (!scratch && !accumulate) ICRL_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, st, x, ldx, rows, cols,
-                       rows_per_block, out);
+                       rows_per_block, out, scratch);
+    if (scratch)
+        hipLaunchKernelGGL(colsum_finish, dim3((cols + 63) / 64), dim3(256), 0, st, scratch, row_blocks, cols, out,
+                           accumulate);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int64_t icrl_embedding_grad_work_ints(int vocab, int rows) {
+    return vocab > 0 && rows > 0 ? (2 + EMB_SLICES) * (int64_t)vocab + rows : 0;
+}
+
+extern "C" int icrl_token_order(const int64_t* idx, int64_t idx_stride, int rows, int vocab, int32_t* work,
+                                icrl_stream_t stream) {
+    ICRL_REQUIRE(idx && work && rows > 0 && vocab > 0, "icrl_token_order: null pointer or empty shape");
+    hipStream_t st = as_stream(stream);
+    // work: count[vocab], offset[vocab], order[rows], then the per-slice counts / starts [EMB_SLICES][vocab]
+    int* count = work;
+    int* offset = work + vocab;
+    int* order = work + 2 * (int64_t)vocab;
+    int* slice_count = order + rows;
+    const dim3 grid((vocab + 255) / 256, EMB_SLICES);
+    hipLaunchKernelGGL(emb_rows_of_token<false>, grid, dim3(256), 0, st, idx, idx_stride, rows, vocab, slice_count,
+                       (int*)nullptr);
+    hipLaunchKernelGGL(emb_offsets, dim3(1), dim3(1024), 0, st, slice_count, vocab, count, offset);
+    hipLaunchKernelGGL(emb_rows_of_token<true>, grid, dim3(256), 0, st, idx, idx_stride, rows, vocab, slice_count, order);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_embedding_grad(float* grad_table, int vocab, int width, const float* rows_in, const int32_t* work,
+                                   icrl_stream_t stream) {
+    ICRL_REQUIRE(grad_table && rows_in && work && vocab > 0, "icrl_embedding_grad: null pointer or empty shape");
+    ICRL_REQUIRE(width % 4 == 0 && reinterpret_cast<uintptr_t>(grad_table) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(rows_in) % 16 == 0, "icrl_embedding_grad: width %% 4 and 16-byte alignment required");
+    hipLaunchKernelGGL(emb_sum_rows, dim3(vocab), dim3(128), 0, as_stream(stream), rows_in, width, work, work + vocab,
+                       work + 2 * (int64_t)vocab, grad_table);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -284,6 +284,11 @@ class A2CEngine:
         # 5 of an activation gradient
         scratch = max(16 * 4 * H * H, 8 * (self.vocab or 0) * H, 5 * l_cols * n * max(widths))
         ws["scratch_main"], ws["scratch_side"] = f32(scratch), f32(scratch)
+        # fixed-order reductions (bias gradients, embedding gradients): the same bits on every run
+        cs = max(2048 * 64 + max(self.vocab or 0, 4 * H), n * 512)
+        ws["cs_main"], ws["cs_side"] = f32(cs), f32(cs)
+        vmax = self._emb_vocab() if (self.P is not None or self.V is not None) else 1
+        ws["emb_work"] = torch.zeros(hip.embedding_grad_work_ints(vmax, l_cols * n), dtype=torch.int32, device=dev)
         k = n if self.per_sample else self._segments_for(tv, tv)
         if k:
             ws["work_v"] = f32(hip.chain_seg_workspace_floats(k))
@@ -466,6 +471,7 @@ class A2CEngine:
         ws = self._buffers(n, 1, s)
         ws["tokT"].copy_(captions.t())
         self._rollout(ws, features, n, 1, s, None, hip.FORCED)
+        self._order_tokens(ws, n, s * n, torch.cuda.current_stream(), torch.cuda.current_stream())
         hip.masked_nll(ws["logp"], valid_steps, row_weight, ws["scalars"][0:1], ws["dlogp"])
         self._policy_backward(ws, features, n, 1, s)
         return ws["scalars"][0:1]
@@ -483,6 +489,7 @@ class A2CEngine:
         hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, p0 * n, ws["Xv"])
         hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
                  bias2=V["valrnn.lstm.bias_hh_l0"])
+        self._order_tokens(ws, n, p0 * n, main, main)
         # the chain starts from zeros (the loop resets the state every minibatch), so a long one runs
         # segment-parallel under the same seam checks and warm-up ladders as the A2C step
         plans = self._plans(ws)
@@ -552,7 +559,9 @@ class A2CEngine:
                       dve=f32(n, 512), d_emit=f32(1, n, H), dgx=f32(pos, 3 * H), dgh=f32(pos, 3 * H), hprev=f32(pos, H),
                       dX=f32(pos, er), scratch=f32(max(16 * 3 * H * H, 16 * 512 * max(512, self.F))),
                       sync=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev),
-                      status=torch.zeros(4, dtype=torch.int32, device=dev),
+                      status=torch.zeros(4, dtype=torch.int32, device=dev), cs=f32(2048 * 64 + 4 * H),
+                      emb_work=torch.zeros(hip.embedding_grad_work_ints(R["rewrnn.caption_embedding.weight"].shape[0], pos),
+                                           dtype=torch.int32, device=dev),
                       seam=torch.zeros(6, dtype=torch.float32, device=dev), segments=self._segments_for(pos))
             if ws["segments"]:
                 ws["work"] = f32(hip.chain_seg_workspace_floats(ws["segments"]))
@@ -615,9 +624,9 @@ class A2CEngine:
         hip.gemm(ws["dS"], ws["se"], ws["dve"], b_kmajor=True)                 # dve = dS . se
         hip.gemm(ws["dS"], ws["ve"], ws["dse"], a_kmajor=True, b_kmajor=True)  # dse = dS^T . ve
         hip.gemm_auto(ws["dve"], features, gR["visual_embed.weight"], sc, a_kmajor=True, b_kmajor=True)
-        hip.colsum(ws["dve"], gR["visual_embed.bias"])
+        hip.colsum(ws["dve"], gR["visual_embed.bias"], scratch=ws["cs"])
         hip.gemm_auto(ws["dse"], hr, gR["semantic_embed.weight"], sc, a_kmajor=True, b_kmajor=True)
-        hip.colsum(ws["dse"], gR["semantic_embed.bias"])
+        hip.colsum(ws["dse"], gR["semantic_embed.bias"], scratch=ws["cs"])
         hip.gemm(ws["dse"], R["semantic_embed.weight"], ws["d_emit"].view(n, H), b_kmajor=True)
         # ---- backward: the chain, then its weight gradients as products over all positions
         if plan_b[0] == "segmented":
@@ -628,14 +637,14 @@ class A2CEngine:
                               ws["status"][1:2])
         hip.chain_hprev(ws["saved"], pos, ws["hprev"], gru=True)
         hip.gemm_auto(ws["dgh"], ws["hprev"], gR["rewrnn.gru.weight_hh_l0"], sc, a_kmajor=True, b_kmajor=True)
-        hip.colsum(ws["dgh"], gR["rewrnn.gru.bias_hh_l0"])
+        hip.colsum(ws["dgh"], gR["rewrnn.gru.bias_hh_l0"], scratch=ws["cs"])
         hip.gemm_auto(ws["dgx"], ws["X"], gR["rewrnn.gru.weight_ih_l0"], sc, a_kmajor=True, b_kmajor=True)
-        hip.colsum(ws["dgx"], gR["rewrnn.gru.bias_ih_l0"])
+        hip.colsum(ws["dgx"], gR["rewrnn.gru.bias_ih_l0"], scratch=ws["cs"])
         g_emb = gR.get("rewrnn.caption_embedding.weight")
         if g_emb is not None:
             hip.gemm_auto(ws["dgx"], w_ih, ws["dX"], sc, b_kmajor=True)
-            g_emb.zero_()
-            hip.scatter_add_rows(g_emb, tok, 1, pos, ws["dX"])
+            hip.token_order(tok, 1, pos, g_emb.shape[0], ws["emb_work"])
+            hip.embedding_grad(g_emb, pos, ws["dX"], ws["emb_work"])
 
     # ------------------------------------------------------------------ the step
     def step(self, features, prefix, n_steps, uniforms=None, forced_tokens=None, mode=hip.SAMPLE, backward=True):
@@ -674,6 +683,8 @@ class A2CEngine:
         self._rollout(ws, features, n, p0, s, uniforms, mode)
         self._mark("rollout_done")
         main.wait_event(ev_feat)
+        if backward and mode != hip.GREEDY:
+            self._order_tokens(ws, n, (p0 - 1 + s) * n, main, side)
         last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
@@ -760,6 +771,34 @@ class A2CEngine:
                ws["rewards"].view(s, n).t().contiguous())
         return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pv, pb), pr, status_host, full_calls=fc)
+
+    def _order_tokens(self, ws, n, rows, main, side):
+        """The rows of the token matrix listed by token (what the reproducible embedding gradients sum by): it
+        needs the tokens only, and both trainable embedding tables are looked up with the same ones, so it is
+        built once per minibatch, on the side stream, where the gradients that use it are computed later."""
+        if not any(g is not None and g.get(k) is not None for g, k in
+                   ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
+            return
+        if side is main:
+            hip.token_order(ws["tokT"].view(-1), 1, rows, self._emb_vocab(), ws["emb_work"])
+            return
+        # on the third stream (idle until the replay check), so that it delays neither the chains' input
+        # products on the side stream nor the chains; the side stream picks the result up from there
+        check = self._check_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(check):
+            check.wait_event(ev)
+            hip.token_order(ws["tokT"].view(-1), 1, rows, self._emb_vocab(), ws["emb_work"])
+            done = torch.cuda.Event()
+            done.record(check)
+        ws["ev_order"] = done
+
+    def _emb_vocab(self):
+        sizes = {g[k].shape[0] for g, k in ((self.P, "caption_embedding.weight"), (self.V, "valrnn.caption_embedding.weight"))
+                 if g is not None}
+        assert len(sizes) == 1, "the policy and value networks are built over one vocabulary"
+        return sizes.pop()
 
     def _replay_rejected(self, n, p0, fc):
         """A replay that was left out did not come back to its start state within the steps checked: ask
@@ -917,13 +956,13 @@ class A2CEngine:
         hip.gemm(dvalue, V["linear2.weight"], dY, b_kmajor=True)                       # dY = dvalue (x) w2
         sm = ws["scratch_main"]   # the two long-k weight gradients are split over k (partial slabs in scratch)
         hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], sm, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
-        hip.colsum(dvalue, gV["linear2.bias"])
+        hip.colsum(dvalue, gV["linear2.bias"], scratch=ws["cs_main"])
         w1, gw1 = V["linear1.weight"], gV["linear1.weight"]
         hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], sm, a_kmajor=True, b_kmajor=True)
         gw1[:, self.F:].copy_(ws["gw1h"])
-        hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1))
+        hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1), scratch=ws["cs_main"])
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
-        hip.colsum(dY, gV["linear1.bias"])
+        hip.colsum(dY, gV["linear1.bias"], scratch=ws["cs_main"])
         hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
 
     def _value_chain_backward(self, ws, n, p0, s, fc, main, side, plan, ev_loss, features=None):
@@ -956,6 +995,8 @@ class A2CEngine:
             if ev_loss is not None:
                 side.wait_event(ev_loss)
                 self._mark("side:policy_bwd_start")
+                if ws.get("ev_order") is not None:
+                    side.wait_event(ws.pop("ev_order"))
                 self._policy_backward(ws, features, n, p0, s)
                 self._mark("side:policy_bwd_done")
                 self._ev_policy = torch.cuda.Event()
@@ -968,13 +1009,12 @@ class A2CEngine:
                 dgsum = ws["dGsum"]
                 hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
             hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
-            hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"])
+            hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_side"])
             gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
             g_emb = gV.get("valrnn.caption_embedding.weight")
             if g_emb is not None:
                 hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], ss, b_kmajor=True)
-                g_emb.zero_()
-                hip.scatter_add_rows(g_emb, tok_flat, 1, lv * n, ws["dXv"])
+                hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
             self._mark("side:value_input_grads_done")
             ev_side = torch.cuda.Event()
             ev_side.record(side)
@@ -1001,7 +1041,7 @@ class A2CEngine:
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
         ss = ws["scratch_side"]
         hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True)
-        hip.colsum(G, gP["linear2vocab.bias"])
+        hip.colsum(G, gP["linear2vocab.bias"], scratch=ws["cs_side"])
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
@@ -1019,12 +1059,11 @@ class A2CEngine:
         hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True, shared=True)
         hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,
                       b_kmajor=True, shared=True)
-        hip.colsum(dg_all, gP["lstm.bias_ih_l0"])
+        hip.colsum(dg_all, gP["lstm.bias_ih_l0"], scratch=ws["cs_side"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
             hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True)
-            g_emb.zero_()
-            hip.scatter_add_rows(g_emb, tok_flat, 1, t_steps * n, ws["dX"])
+            hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
         hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True)
-        hip.colsum(ws["dh0"], gP["cnn2linear.bias"])
+        hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])

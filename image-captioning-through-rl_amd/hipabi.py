@@ -43,7 +43,11 @@ SIGNATURES = {
     "icrl_lstm_chain_bwd_seg": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 4),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
-    "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]),
+    "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "icrl_colsum_scratch_floats": (c_i64, [c_int, c_int]),
+    "icrl_embedding_grad_work_ints": (c_i64, [c_int, c_int]),
+    "icrl_token_order": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    "icrl_embedding_grad": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "icrl_lstm_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_gru_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -218,11 +222,41 @@ def scatter_add_rows(grad_table, idx, idx_stride, rows, rows_in):
                                         _ptr(_f32c(rows_in)), _stream()), "icrl_scatter_add_rows")
 
 
-def colsum(x, out, accumulate=False, rows=None):
+def colsum(x, out, accumulate=False, rows=None, scratch=None):
+    """out[c] (+)= sum_r x[r, c].  scratch: a float32 buffer of at least colsum_scratch_floats(rows, cols); with
+    it the result is reproducible bit for bit (fixed summation order), without it float atomics are used."""
     rows = x.shape[0] if rows is None else rows
-    _check(load().icrl_colsum(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(out), int(accumulate), _stream()),
-           "icrl_colsum")
+    if scratch is not None:
+        assert scratch.dtype == torch.float32 and scratch.numel() >= colsum_scratch_floats(rows, x.shape[1])
+    _check(load().icrl_colsum(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(out), int(accumulate), _ptr(scratch),
+                              _stream()), "icrl_colsum")
     return out
+
+
+def colsum_scratch_floats(rows, cols):
+    return int(load().icrl_colsum_scratch_floats(int(rows), int(cols)))
+
+
+def token_order(idx, idx_stride, rows, vocab, work):
+    """For every token the rows that hold it, in ascending order, into work (int32,
+    embedding_grad_work_ints(vocab, rows)): what embedding_grad sums by."""
+    assert idx.dtype == torch.int64 and work.dtype == torch.int32 and work.is_contiguous()
+    assert work.numel() >= embedding_grad_work_ints(vocab, rows) and idx.numel() >= (rows - 1) * idx_stride + 1
+    _check(load().icrl_token_order(_ptr(idx), idx_stride, rows, vocab, _ptr(work), _stream()), "icrl_token_order")
+
+
+def embedding_grad(grad_table, rows, rows_in, work):
+    """grad_table[v] = sum of rows_in[r] over the rows token_order listed for v, in ascending r (reproducible);
+    the whole table is overwritten."""
+    vocab, width = grad_table.shape
+    assert work.dtype == torch.int32 and work.numel() >= embedding_grad_work_ints(vocab, rows)
+    assert rows_in.numel() >= rows * width
+    _check(load().icrl_embedding_grad(_ptr(_f32c(grad_table)), vocab, width, _ptr(_f32c(rows_in)), _ptr(work), _stream()),
+           "icrl_embedding_grad")
+
+
+def embedding_grad_work_ints(vocab, rows):
+    return int(load().icrl_embedding_grad_work_ints(int(vocab), int(rows)))
 
 
 def gru_cell_fwd(gx, gh, h_prev, h):

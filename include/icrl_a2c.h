@@ -75,9 +75,26 @@ int icrl_gather_rows(const float* table, int width, const int64_t* idx, int64_t 
 int icrl_scatter_add_rows(float* grad_table, int width, const int64_t* idx, int64_t idx_stride,
                           int rows, const float* rows_in, icrl_stream_t stream);
 
-/* out[n] (+)= sum_r x[r, n]   (bias gradients) */
+/* The same as an overwrite, reproducible bit for bit (the reference's CPU index_add is; float atomics are
+ * not), in two calls.  icrl_token_order lists, for every token v in [0, vocab), the rows r with
+ * idx[r*idx_stride] == v in ascending r - exact integer work (per-token counts, their exclusive scan,
+ * per-token row lists) kept in `work`, icrl_embedding_grad_work_ints(vocab, rows) int32.  It depends on the
+ * tokens only, so one call serves every embedding table looked up with the same tokens, and it can run as
+ * soon as they exist.  icrl_embedding_grad then writes grad_table[v, :] = the sum of rows_in[r, :] over v's
+ * rows in that order (zeros for tokens no row holds).  Embedding backward of models.py:73, 132 through
+ * trainers.py:479. */
+int64_t icrl_embedding_grad_work_ints(int vocab, int rows);
+int icrl_token_order(const int64_t* idx, int64_t idx_stride, int rows, int vocab, int32_t* work,
+                     icrl_stream_t stream);
+int icrl_embedding_grad(float* grad_table, int vocab, int width, const float* rows_in, const int32_t* work,
+                        icrl_stream_t stream);
+
+/* out[n] (+)= sum_r x[r, n]   (bias gradients).  scratch (may be NULL): icrl_colsum_scratch_floats(rows, cols)
+ * floats; with it the row blocks' partial sums are added in a fixed order (reproducible bit for bit), without
+ * it by float atomics. */
+int64_t icrl_colsum_scratch_floats(int rows, int cols);
 int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
-                icrl_stream_t stream);
+                float* scratch, icrl_stream_t stream);
 
 /* ---- batched LSTM cell (policy network, models.py:80) -----------------------
  * gates_pre[N,4H] holds x*W_ih^T + h*W_hh^T + b_ih + b_hh, PyTorch order i,f,g,o.

@@ -122,9 +122,11 @@ def a2c_minibatch(nets, optimizer, features, captions, uniforms=None):
     loss = (-logps * adv).mean() + 0.5 * adv.pow(2).mean()
     optimizer.zero_grad()
     loss.backward()
+    grad_norms = {name: float(p.grad.norm()) for name, p in nets.named_trainable() if p.grad is not None}
     optimizer.step()
     return dict(tokens=seq.numpy(), loss=float(loss.detach()), mean_reward=float(rewards.mean()),
-                mean_advantage=float(adv.detach().mean()))
+                mean_advantage=float(adv.detach().mean()), values=values.detach().numpy(), rewards=rewards.numpy(),
+                log_probs=logps.detach().numpy(), grad_norms=grad_norms)
 
 
 def make_optimizer(nets):

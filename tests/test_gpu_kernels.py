@@ -547,3 +547,43 @@ def test_segmented_gru_forward_keeps_activations_and_backward_matches_the_exact_
     for got, want in ((gx_s, gx_x), (gh_s, gh_x)):
         scale = want.abs().max().item()
         assert (got - want).abs().max().item() <= 1e-4 * scale, ((got - want).abs().max().item(), scale)
+
+
+def test_reproducible_embedding_gradient_and_column_sums():
+    """icrl_embedding_grad (rows ordered by token, summed in ascending order) and icrl_colsum with a scratch
+    buffer (row blocks' partials added in a fixed order) against float64 sums, and bit-equal from run to run;
+    repeated tokens, unused tokens and a strided index included."""
+    rs = np.random.RandomState(3)
+    vocab, width, rows = 700, 300, 5000
+    idx = rs.randint(0, 40, size=rows) * 17 % vocab          # few distinct tokens: long per-token lists
+    idx[::7] = rs.randint(0, vocab, size=len(idx[::7]))
+    idx2 = np.stack((idx, np.zeros_like(idx)), 1).reshape(-1)  # stride 2
+    x = rnd(rs, rows, width)
+    want = np.zeros((vocab, width))
+    np.add.at(want, idx, x.astype(np.float64))
+    work = torch.zeros(hip.embedding_grad_work_ints(vocab, rows), dtype=torch.int32, device="cuda")
+    xd, id2 = dev(x), torch.from_numpy(idx2).cuda()
+    outs = []
+    for _ in range(3):
+        g = torch.full((vocab, width), 7.0, device="cuda")
+        hip.token_order(id2, 2, rows, vocab, work)
+        hip.embedding_grad(g, rows, xd, work)
+        torch.cuda.synchronize()
+        outs.append(g)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert float(outs[0][np.setdiff1d(np.arange(vocab), idx)].abs().max()) == 0.0
+    # column sums: 9728 x 2048 (many row blocks) and a one-column matrix
+    for r, c in ((9728, 2048), (300, 1), (19, 70000)):
+        m = rnd(rs, r, c)
+        md = dev(m)
+        scratch = torch.zeros(hip.colsum_scratch_floats(r, c), device="cuda")
+        got = []
+        for _ in range(2):
+            o = torch.full((c,), 3.0, device="cuda")
+            hip.colsum(md, o, scratch=scratch)
+            got.append(o)
+        np.testing.assert_allclose(got[0].cpu().numpy(), m.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.equal(got[0], got[1])
+        hip.colsum(md, got[1], accumulate=True, scratch=scratch)
+        np.testing.assert_allclose(got[1].cpu().numpy(), 2 * m.astype(np.float64).sum(0), rtol=1e-4, atol=2e-3)
