@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 PKG = "image-captioning-through-rl_amd"
 
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_32x32x2_f32, dense, MI355X
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16, dense, MI355X
 
 
 def build_networks(syn, models, optim, vocab, fdim, seed, dev, value_forget_bias=0.0):
@@ -236,8 +237,14 @@ def main():
         a[3] += nbytes
         chain_steps[kind] = chain_steps.get(kind, 0) + steps
         chain_flops[kind] = chain_flops.get(kind, 0.0) + flops
-    gemm_kinds = [k for k in acc if k.startswith("gemm")]
-    gemm_flops, gemm_s, gemm_launches, gemm_bytes = (sum(acc[k][j] for k in gemm_kinds) for j in range(4))
+    gemm_flops, gemm_s, gemm_launches, gemm_bytes = acc.get("gemm", [0.0, 1e-30, 0, 0.0])
+    bf16 = None
+    if "gemm_bf16" in acc:   # --policy-dtype bf16: the policy network's products, priced against the bf16 peak
+        bf, bs, bl, bb = acc["gemm_bf16"]
+        bf16 = {"kernel": "gemm_bf16_kernel (policy network products)", "launches_per_step": bl, "gflop_per_step": bf / 1e9,
+                "ms_per_step_in_kernel": 1e3 * bs, "achieved_tflops": bf / bs / 1e12,
+                "frac_of_bf16_mfma_peak": bf / bs / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "algorithmic_bytes_per_launch": bb / max(1, bl)}
     peak = F32_MFMA_PEAK_TFLOPS
     achieved = gemm_flops / gemm_s / 1e12
     pmc_t, pmc_m = load_profile("pmc_traffic.json"), load_profile("pmc_mfma.json")
@@ -318,6 +325,7 @@ def main():
                          "mfma_profile_git_sha": (pmc_m or {}).get("_git_sha"),
                          "mfma_utilisation_note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch cycles * 1024 SIMDs) per kernel, "
                                                   "kernels run one at a time (profiles/pmc_mfma.json)"},
+            "bf16_gemms": bf16,
             "chains": chains,
             "profiled_step": {"plans": profiled_plans, "no_attempt_redone": profiled_clean,
                               "note": "the roofline and chain figures are this step's launches, with this step's plans"},

@@ -1442,10 +1442,20 @@ extern "C" int icrl_gru_chain_bwd_seg(const float* w_hh, const float* saved, con
 }
 
 extern "C" int icrl_chain_pair_supported(int segments) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return segments >= 1 && (H / 32) * ((segments + 31) / 32) <= cus ? 1 : 0;   // two workgroups (80 KB of LDS each) per CU
+    // every workgroup of a persistent launch must be resident at once: 2 x 16 x ceil(segments / 32) of the forward
+    // pair kernel, 16 x ceil(segments / 32) of the backward kernel, against CUs x what the runtime says fits one CU
+    static int cus = -1, per_cu_fwd = 0, per_cu_bwd = 0;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_fwd, seg_fwd_pair_persist, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_bwd, seg_bwd_persist, 256, 0) != hipSuccess) return 0;
+        cus = n;
+    }
+    if (segments < 1) return 0;
+    const int per_chain = (H / 32) * ((segments + 31) / 32);
+    return 2 * per_chain <= cus * per_cu_fwd && per_chain <= cus * per_cu_bwd ? 1 : 0;
 }
 
 extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,

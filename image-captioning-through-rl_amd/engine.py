@@ -170,7 +170,7 @@ class A2CEngine:
     def __init__(self, policy_params, value_params, reward_params, policy_grads=None, value_grads=None,
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
-                 chain_semantics="batch", collapse_replays=True, max_segments=512,
+                 chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1536, 2048), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -187,10 +187,16 @@ class A2CEngine:
         self.chain_mode, self.segments, self.warmups = chain_mode, segments, tuple(warmups)
         self.fallbacks = 0  # how many times a seam or replay check rejected an attempt
         self.collapse = collapse_replays and not self.per_sample
+        # arithmetic of the policy network's products (models.py:75, 80, 82 and their backward): "f32" = exact
+        # float32 matrix instruction (default; greedy ids bit-exact), "bf16" = operands rounded to bf16 on chip,
+        # float32 sums.  The chains, heads, softmax / sampler and every reduction stay float32 either way.
+        assert policy_dtype in ("f32", "bf16")
+        self.pd = policy_dtype
         self.max_segments = int(max_segments)
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
         self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
         self.last_replay = None      # (full_calls, steps, err value chain, err reward chain) of the last step
+        self.launch_timeouts = 0     # attempts repeated because a persistent launch gave up waiting for a workgroup
         self._check = None           # third stream: the replay check runs beside the backward pass
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
         # on_policy_grads(event): called once per step as soon as the forward pass has been accepted, with
@@ -439,8 +445,8 @@ class A2CEngine:
         # h0 = cnn2linear(features): a 64-tile output with a long k, first on the step's critical path; k is
         # split over workgroups (partial slabs summed on top of the bias)
         Hb[0].copy_(P["cnn2linear.bias"].expand_as(Hb[0]))
-        hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True)
-        fused_step = self.E % 64 == 0
+        hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True, dtype=self.pd)
+        fused_step = self.E % 64 == 0 and self.pd == "f32"
         for k in range(t_steps):
             if fused_step:  # gather + both gate products + cell in one launch
                 hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k], P["lstm.weight_ih_l0"],
@@ -449,12 +455,12 @@ class A2CEngine:
             else:
                 hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
                 hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"],
-                         bias2=P["lstm.bias_hh_l0"])
-                hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True)
+                         bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
+                hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True, dtype=self.pd)
                 hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
             if k >= p0 - 1:
                 st = k - (p0 - 1)
-                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"])
+                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"], dtype=self.pd)
                 hip.sample_tokens(ws["logits"], mode, tokT[k + 1], 1,
                                   uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
                                   log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
@@ -689,6 +695,7 @@ class A2CEngine:
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
         status_host = None
+        gave_up = 0   # attempts whose persistent launch gave up waiting for a workgroup (reported as an infinite error)
         # ---- chains forward + loss + backward, enqueued in one go; the forward seam errors come back
         # through pinned memory as soon as the chains are done, so the host knows whether the attempt
         # stands while the device is still busy with the backward pass.  A rejected forward seam or replay
@@ -712,6 +719,12 @@ class A2CEngine:
                 ok_v, ok_r = (all(e <= t for e, t in c) for c in (checks_v, checks_r))
                 if not (ok_v and ok_r):
                     self.fallbacks += 1
+                    if gave_up == 0 and any(e == float("inf") for e, _ in checks_v + checks_r):
+                        # +inf is what a launch reports whose workgroups were not all resident in time (other
+                        # kernels held the CUs): that says nothing about the warm-up, so the same plans run once more
+                        gave_up += 1
+                        self.launch_timeouts += 1
+                        continue
                     if not ok_v:
                         fv = self._next_rung(fv, checks_v)
                         self._ladder_fv.rejected(fv)
@@ -1040,30 +1053,30 @@ class A2CEngine:
         hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G, tok_flat[p0 * n:], 1, ws["dlogp"])
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
         ss = ws["scratch_side"]
-        hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True)
+        hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(G, gP["linear2vocab.bias"], scratch=ws["cs_side"])
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
-        hip.gemm_auto(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), ss, b_kmajor=True, shared=True)
+        hip.gemm_auto(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), ss, b_kmajor=True, shared=True, dtype=self.pd)
         dgp = ws["dgp"]
         dc = [ws["dc0"], ws["dc1"]]
         for k in range(t_steps - 1, -1, -1):
             hip.lstm_cell_bwd(ws["gates"][k], ws["Cbuf"][k], ws["Cbuf"][k + 1], dHall[k],
                               None if k == t_steps - 1 else dc[(k + 1) & 1], dgp[k], dc[k & 1])
             if k > 0:
-                hip.gemm_auto(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], ss, b_kmajor=True, accumulate=True, shared=True)
+                hip.gemm_auto(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], ss, b_kmajor=True, accumulate=True, shared=True, dtype=self.pd)
             else:
-                hip.gemm_auto(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], ss, b_kmajor=True, shared=True)
+                hip.gemm_auto(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], ss, b_kmajor=True, shared=True, dtype=self.pd)
         dg_all = dgp.view(t_steps * n, 4 * H)
-        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True, shared=True)
+        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,
-                      b_kmajor=True, shared=True)
+                      b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(dg_all, gP["lstm.bias_ih_l0"], scratch=ws["cs_side"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
-            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True)
+            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True, dtype=self.pd)
             hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
-        hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True)
+        hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])

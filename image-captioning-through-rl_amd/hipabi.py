@@ -23,6 +23,10 @@ SIGNATURES = {
                               c_vp, c_vp, c_int, c_int, c_vp]),
     "icrl_gemm_f32_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
                                      c_int, c_int, c_vp]),
+    "icrl_gemm_bf16": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int,
+                               c_vp, c_vp, c_int, c_int, c_vp]),
+    "icrl_gemm_bf16_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
+                                      c_int, c_int, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 6),
@@ -182,8 +186,10 @@ def _f32c(t):
 
 
 def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, bias2=None, accumulate=False,
-         m=None, n=None, k=None, lda=None, ldb=None, ldc=None, tile=0):
+         m=None, n=None, k=None, lda=None, ldb=None, ldc=None, tile=0, dtype="f32"):
     """out[M,N] (+)= A[M,K] @ B[K,N] (+ bias + bias2).  tile: 0 = by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64.
+    dtype "bf16": operands rounded to bf16 on chip, products on the bf16 matrix instruction, float32 sums
+    (tiles 1 and 3 only).
 
     a: stored [M, K] (a_kmajor False) or [K, M] (True); b: stored [N, K] (False, an
     nn.Linear weight) or [K, N] (True).  2-D tensors whose last dimension is contiguous;
@@ -203,11 +209,15 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     ldc = out.stride(0) if ldc is None else ldc
     if a_rows is not None:
         assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
-    with _Timed("gemm", 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
-        rc = load().icrl_gemm_f32(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor),
-                                  _ptr(out), ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), int(tile),
-                                  _stream())
-    _check(rc, "icrl_gemm_f32")
+    assert dtype in ("f32", "bf16")
+    if dtype == "bf16":
+        fn, kind, tile = load().icrl_gemm_bf16, "gemm_bf16", (1 if tile == 2 else tile)
+    else:
+        fn, kind = load().icrl_gemm_f32, "gemm"
+    with _Timed(kind, 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
+        rc = fn(_ptr(a), lda, int(a_kmajor), _ptr(a_rows), _ptr(b), ldb, int(b_kmajor),
+                _ptr(out), ldc, m, n, k, _ptr(bias), _ptr(bias2), int(accumulate), int(tile), _stream())
+    _check(rc, "icrl_gemm_" + dtype)
     return out
 
 
@@ -398,16 +408,20 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
            "icrl_adam_step")
 
 
-def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0):
+def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0, dtype="f32"):
     """slabs[z] = partial product of split z; slabs is [splits, M, N] contiguous."""
     m = a.shape[1] if a_kmajor else a.shape[0]
     k = a.shape[0] if a_kmajor else a.shape[1]
     n = b.shape[1] if b_kmajor else b.shape[0]
     assert slabs.shape == (splits, m, n) and slabs.is_contiguous()
-    with _Timed("gemm", 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
-        rc = load().icrl_gemm_f32_splitk(_ptr(a), a.stride(0), int(a_kmajor), _ptr(b), b.stride(0), int(b_kmajor),
-                                         _ptr(slabs), n, m * n, m, n, k, splits, int(tile), _stream())
-    _check(rc, "icrl_gemm_f32_splitk")
+    if dtype == "bf16":
+        fn, kind, tile = load().icrl_gemm_bf16_splitk, "gemm_bf16", (1 if tile == 2 else tile)
+    else:
+        fn, kind = load().icrl_gemm_f32_splitk, "gemm"
+    with _Timed(kind, 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
+        rc = fn(_ptr(a), a.stride(0), int(a_kmajor), _ptr(b), b.stride(0), int(b_kmajor),
+                _ptr(slabs), n, m * n, m, n, k, splits, int(tile), _stream())
+    _check(rc, "icrl_gemm_%s_splitk" % dtype)
 
 
 def sum_slabs(slabs, out, accumulate=False):
@@ -454,7 +468,8 @@ def plan_gemm(m, n, k, out_contiguous=True, shared=False):
     return 1, best[1]
 
 
-def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None, shared=False):
+def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None, shared=False,
+              dtype="f32"):
     """gemm() with the tile / split-K choice of plan_gemm(); `scratch` is a flat float32 buffer for
     the split-K partial slabs (summed in a fixed order, so results are reproducible)."""
     m = a.shape[1] if a_kmajor else a.shape[0]
@@ -466,10 +481,10 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:
         slabs = scratch[:splits * m * n].view(splits, m, n)
-        gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor, tile=tile)
+        gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor, tile=tile, dtype=dtype)
         sum_slabs(slabs, out, accumulate=accumulate)
         return out
-    return gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias, tile=tile)
+    return gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias, tile=tile, dtype=dtype)
 
 
 def chain_seg_workspace_floats(segments):

@@ -166,8 +166,15 @@ class ValueNetworkRNN(nn.Module):
             self.hidden_cell = (h.view(1, n, H), c.view(1, n, H))
             return h
         state = torch.cat((self.hidden_cell[0].reshape(-1), self.hidden_cell[1].reshape(-1))).to(dev).contiguous()
-        state_out = torch.empty_like(state)
         h_emit = torch.empty(1, n, H, device=dev)
+        if p * n >= SEGMENTED_MIN_POSITIONS:
+            # a long chain runs segment-parallel from the carried state (the first segment picks it up; the
+            # others warm up from zeros and are checked at their seams), exact walk if no warm-up passes
+            saved = torch.empty(p * n, 6, H, device=dev)
+            if self._forward_segmented(xproj, n, p, h_emit, saved, state):
+                self.hidden_cell = (saved[-1, 5].view(1, 1, H).clone(), saved[-1, 4].view(1, 1, H).clone())
+                return h_emit[0]
+        state_out = torch.empty_like(state)
         sync, status = self._chain_ws.get(dev)
         hip.lstm_chain_fwd(xproj, self.lstm.weight_hh_l0, n, p, 1, h_emit, None, sync, status, state_in=state,
                            state_out=state_out)
@@ -175,6 +182,25 @@ class ValueNetworkRNN(nn.Module):
             raise RuntimeError("value LSTM chain kernel timed out")
         self.hidden_cell = (state_out[:H].view(1, 1, H), state_out[H:].view(1, 1, H))
         return h_emit[0]
+
+    def _forward_segmented(self, xproj, n, columns, h_emit, saved, state):
+        """One call's chain (columns * n positions) cut into segments that run side by side after a warm-up
+        (icrl_lstm_chain_fwd_seg with the carried state as state_in).  Accepted only if every seam agrees to
+        rounding; the warm-up that passed is tried first next time.  False: the caller walks the chain exactly."""
+        dev = xproj.device
+        positions = columns * n
+        segments = max(32, min(512, positions // 16 // 32 * 32))
+        if self._seg_work is None or self._seg_work.numel() < hip.chain_seg_workspace_floats(segments):
+            self._seg_work = torch.empty(hip.chain_seg_workspace_floats(segments), device=dev)
+            self._seg_err = torch.zeros(2, device=dev)
+        for warmup in (w for w in SEGMENTED_WARMUPS if w >= self._seg_warmup):
+            hip.lstm_chain_fwd_seg(xproj, self.lstm.weight_hh_l0, n, columns, 1, segments, warmup, h_emit, saved,
+                                   self._seg_work, self._seg_err, state_in=state,
+                                   persistent=hip.chain_pair_supported(segments))
+            if self._seg_err[0].item() <= SEGMENTED_SEAM_TOL:
+                self._seg_warmup = warmup
+                return True
+        return False
 
     @torch.no_grad()
     def forward_columns_many(self, tok_list):
@@ -205,19 +231,7 @@ class ValueNetworkRNN(nn.Module):
         state = torch.cat((self.hidden_cell[0].reshape(-1), self.hidden_cell[1].reshape(-1))).to(dev).contiguous()
         saved = torch.empty(positions, 6, H, device=dev)
         h_emit = torch.empty(1, n, H, device=dev)
-        done = False
-        if positions >= SEGMENTED_MIN_POSITIONS:
-            segments = max(32, min(512, positions // 16 // 32 * 32))
-            if self._seg_work is None or self._seg_work.numel() < hip.chain_seg_workspace_floats(segments):
-                self._seg_work = torch.empty(hip.chain_seg_workspace_floats(segments), device=dev)
-                self._seg_err = torch.zeros(2, device=dev)
-            for warmup in (w for w in SEGMENTED_WARMUPS if w >= self._seg_warmup):
-                hip.lstm_chain_fwd_seg(xproj, self.lstm.weight_hh_l0, n, calls * p, 1, segments, warmup, h_emit, saved,
-                                       self._seg_work, self._seg_err, state_in=state,
-                                       persistent=hip.chain_pair_supported(segments))
-                if self._seg_err[0].item() <= SEGMENTED_SEAM_TOL:
-                    self._seg_warmup, done = warmup, True
-                    break
+        done = positions >= SEGMENTED_MIN_POSITIONS and self._forward_segmented(xproj, n, calls * p, h_emit, saved, state)
         if not done:
             sync, status = self._chain_ws.get(dev)
             hip.lstm_chain_fwd(xproj, self.lstm.weight_hh_l0, n, calls * p, 1, h_emit, saved, sync, status,

@@ -232,13 +232,15 @@ def _a2c_minibatch(engine, optimizer, captions, features, p0, n_steps):
 
 
 def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size, epochs,
-                 chain_semantics="batch"):
+                 chain_semantics="batch", policy_dtype="f32"):
     """Advantage-weighted policy-gradient training (trainers.py:402-500).  chain_semantics="per_sample"
     gives every image its own recurrent state in the value / reward networks (what the reference
-    computes at batch_size 1) instead of one recurrence through all rows of the minibatch."""
+    computes at batch_size 1) instead of one recurrence through all rows of the minibatch.
+    policy_dtype="bf16": the policy network's products in bf16 with float32 sums (an opt-in; the default is
+    exact float32)."""
     writer = make_writer(plot_dir)
     print_green('[Training] Training Advantage Actor-Critic Network')
-    engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics)
+    engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics, policy_dtype=policy_dtype)
     ddp.decorrelate_numpy_stream()
     best_loss = float('inf')
     for epoch in range(epochs):
@@ -259,14 +261,14 @@ def a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, s
 
 
 def a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths, batch_size,
-                            epochs, curriculum, chain_semantics="batch"):
+                            epochs, curriculum, chain_semantics="batch", policy_dtype="f32"):
     """Curriculum variant (trainers.py:503-616): for each level, start from the
     ground-truth prefix captions[:, :caplen-level] and roll out `level` steps; minibatches
     whose captions are too short for the level are skipped."""
     writer = make_writer(plot_dir)
     print_green('[Training] Training Advantage Actor-Critic Network')
     print_green(f'[Training] mode set to curriculum training using levels: {curriculum}')
-    engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics)
+    engine = build_engine(a2c_network, reward_network, chain_semantics=chain_semantics, policy_dtype=policy_dtype)
     ddp.decorrelate_numpy_stream()
     for level in curriculum:
         print_green(f'[Training] Training curriculum level: {level}')
@@ -434,7 +436,7 @@ def _load_or_train(make, path, what, train):
 
 
 def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirectional, epochs, batch_size,
-                      retrain_all=False, curriculum=None, chain_semantics="batch"):
+                      retrain_all=False, curriculum=None, chain_semantics="batch", policy_dtype="f32"):
     """Entry point (trainers.py:312-399): the three pre-trained networks are loaded from their
     checkpoints (or trained by their pre-training loops when a file is missing, or all of them with
     retrain_all), the reward network is frozen, Adam(lr=1e-4) runs over value + policy, the plain or
@@ -488,13 +490,13 @@ def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirecti
     save_paths = [model_save_path, network_paths["a2c_network"]]
     if curriculum is None:
         a2c_network = a2c_training(train_data, a2c_network, reward_network, optimizer, plot_dir, save_paths,
-                                   batch_size, epochs, chain_semantics=chain_semantics)
+                                   batch_size, epochs, chain_semantics=chain_semantics, policy_dtype=policy_dtype)
     else:
         if 16 not in curriculum:
             curriculum.append(16)  # Final Curriculum Level, ie Full Training
         a2c_network = a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir,
                                               save_paths, batch_size, epochs, curriculum,
-                                              chain_semantics=chain_semantics)
+                                              chain_semantics=chain_semantics, policy_dtype=policy_dtype)
     if ddp.is_main():
         with open(results_save_path, 'a') as f:
             f.write('\n' + '-' * 10 + ' network ' + '-' * 10 + '\n')

@@ -63,6 +63,19 @@ int icrl_gemm_f32_splitk(const float* A, int64_t lda, int a_kmajor, const float*
                          int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
                          int N, int K, int splits, int tile, icrl_stream_t stream);
 
+/* The same two products with bf16 arithmetic: operands and result stay float32 in memory, every operand tile is
+ * rounded to bf16 (nearest even) on its way into LDS, products run on v_mfma_f32_32x32x16_bf16 and accumulate
+ * in float32.  An opt-in for the policy network's products (models.py:75, 80, 82 and their autograd
+ * transposes); the recurrent chains and everything the default path computes stay exact float32.
+ * tile: 0 = by shape, 1 = 128x128, 3 = 64x64. */
+int icrl_gemm_bf16(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
+                   const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
+                   int M, int N, int K, const float* bias, const float* bias2,
+                   int accumulate, int tile, icrl_stream_t stream);
+int icrl_gemm_bf16_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
+                          int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
+                          int N, int K, int splits, int tile, icrl_stream_t stream);
+
 /* out[i] = (accumulate ? out[i] : 0) + sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
 int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
                    int accumulate, icrl_stream_t stream);

@@ -587,3 +587,45 @@ def test_reproducible_embedding_gradient_and_column_sums():
         assert torch.equal(got[0], got[1])
         hip.colsum(md, got[1], accumulate=True, scratch=scratch)
         np.testing.assert_allclose(got[1].cpu().numpy(), 2 * m.astype(np.float64).sum(0), rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("a_km", [False, True])
+@pytest.mark.parametrize("b_km", [False, True])
+@pytest.mark.parametrize("shape", [(70, 130, 77), (512, 2048, 1024), (256, 1000, 300), (33, 64, 5), (200, 10000, 512)])
+def test_bf16_gemm_layouts(a_km, b_km, shape):
+    """icrl_gemm_bf16: operands rounded to bf16 (nearest even), exact products, float32 sums - against the same
+    rounding followed by a float64 product; bias, accumulate, ragged edges, both tile sizes."""
+    m, n, k = shape
+    rs = np.random.RandomState(m + n + k)
+    a = rnd(rs, *((k, m) if a_km else (m, k)))
+    b = rnd(rs, *((k, n) if b_km else (n, k)))
+    bias = rnd(rs, n)
+    a64 = torch.from_numpy(a).bfloat16().double()
+    b64 = torch.from_numpy(b).bfloat16().double()
+    want = ((a64.t() if a_km else a64) @ (b64 if b_km else b64.t())).numpy()
+    scale = np.sqrt(k)
+    for tile in (1, 3):
+        out = torch.full((m, n), 9.0, device="cuda")
+        hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, bias=dev(bias), tile=tile, dtype="bf16")
+        np.testing.assert_allclose(out.cpu().numpy(), want + bias, rtol=1e-5, atol=2e-6 * scale)
+        hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, accumulate=True, tile=tile, dtype="bf16")
+        np.testing.assert_allclose(out.cpu().numpy(), 2 * want + bias, rtol=1e-5, atol=4e-6 * scale)
+    # split-K slabs through the planner
+    scratch = torch.zeros(8 * m * n, device="cuda")
+    out = torch.zeros(m, n, device="cuda")
+    if not a_km and not b_km:
+        slabs = scratch[:3 * m * n].view(3, m, n)
+        hip.gemm_splitk(dev(a), dev(b), slabs, 3, dtype="bf16")
+        hip.sum_slabs(slabs, out)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=2e-6 * scale)
+
+
+def test_bf16_gemm_with_row_gather_and_strided_output():
+    rs = np.random.RandomState(8)
+    table, w = rnd(rs, 50, 96), rnd(rs, 40, 96)
+    idx = rs.randint(0, 50, size=77)
+    out = torch.zeros(77, 64, device="cuda")
+    hip.gemm(dev(table), dev(w), out[:, 8:48], a_rows=torch.from_numpy(idx).cuda(), dtype="bf16")
+    want = torch.from_numpy(table[idx]).bfloat16().double() @ torch.from_numpy(w).bfloat16().double().t()
+    np.testing.assert_allclose(out[:, 8:48].cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-5)
+    assert float(out[:, :8].abs().max()) == 0.0 and float(out[:, 48:].abs().max()) == 0.0
