@@ -49,9 +49,10 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict
 // stride it) and adds its partial to out[] with one float atomic per column.
 // partials != null: the workgroup's partial goes to partials[blockIdx.y][col] instead, and colsum_finish adds
 // the row blocks' partials in a fixed order (same bits on every run, which float atomics do not give).
+// row_scale != null: out[n] = sum_r row_scale[r] * x[r, n].
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ldx, int rows,
                                                      int cols, int rows_per_block, float* __restrict__ out,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, const float* __restrict__ row_scale) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -59,8 +60,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     float s0 = 0.f, s1 = 0.f;
     if (col < cols) {
         int r = r0 + wave;
-        for (; r + 4 < r1; r += 8) { s0 += x[(int64_t)r * ldx + col]; s1 += x[(int64_t)(r + 4) * ldx + col]; }
-        if (r < r1) s0 += x[(int64_t)r * ldx + col];
+        if (row_scale) {
+            for (; r + 4 < r1; r += 8) {
+                s0 = fmaf(row_scale[r], x[(int64_t)r * ldx + col], s0);
+                s1 = fmaf(row_scale[r + 4], x[(int64_t)(r + 4) * ldx + col], s1);
+            }
+            if (r < r1) s0 = fmaf(row_scale[r], x[(int64_t)r * ldx + col], s0);
+        } else {
+            for (; r + 4 < r1; r += 8) { s0 += x[(int64_t)r * ldx + col]; s1 += x[(int64_t)(r + 4) * ldx + col]; }
+            if (r < r1) s0 += x[(int64_t)r * ldx + col];
+        }
     }
     part[wave][lane] = s0 + s1;
     __syncthreads();
@@ -464,9 +473,23 @@ __global__ __launch_bounds__(256) void policy_dlogits_kernel(const float* p, flo
     const int64_t total = (int64_t)rows * V;
     for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int r = (int)(e / V), k = (int)(e % V);
-        const float c = coef[r];
+        const float c = coef ? coef[r] : 1.f;
         const float hot = (tokens[r * token_stride] == (int64_t)k) ? 1.f : 0.f;
         g[e] = c * (hot - p[e]);
+    }
+}
+
+// out[r, :] = coef[r] * x[r, :]  (cols % 4 == 0, 16-byte aligned rows)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ coef, float* __restrict__ out,
+                                                         int64_t ldo, int rows, int c4) {
+    const int64_t total = (int64_t)rows * c4;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / c4), c = (int)(e - (int64_t)r * c4);
+        const float k = coef[r];
+        float4 v = reinterpret_cast<const float4*>(x + (int64_t)r * ldx)[c];
+        v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+        reinterpret_cast<float4*>(out + (int64_t)r * ldo)[c] = v;
     }
 }
 
@@ -594,7 +617,7 @@ extern "C" int64_t icrl_colsum_scratch_floats(int rows, int cols) {
 }
 
 extern "C" int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
-                           float* scratch, icrl_stream_t stream) {
+                           const float* row_scale, float* scratch, icrl_stream_t stream) {
     ICRL_REQUIRE(x && out && rows > 0 && cols > 0, "icrl_colsum: null pointer or empty shape");
     hipStream_t st = as_stream(stream);
     const int col_blocks = (cols + 63) / 64;
@@ -602,7 +625,7 @@ extern "C" int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, floa
     const int rows_per_block = (rows + row_blocks - 1) / row_blocks;
     if (!scratch && !accumulate) ICRL_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, st, x, ldx, rows, cols,
-                       rows_per_block, out, scratch);
+                       rows_per_block, out, scratch, row_scale);
     if (scratch)
         hipLaunchKernelGGL(colsum_finish, dim3((cols + 63) / 64), dim3(256), 0, st, scratch, row_blocks, cols, out,
                            accumulate);
@@ -731,10 +754,21 @@ extern "C" int icrl_vse_loss(const float* S, int N, float beta, float* row_scrat
 
 extern "C" int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, const int64_t* tokens,
                                    int64_t token_stride, const float* coef, icrl_stream_t stream) {
-    ICRL_REQUIRE(probs && dlogits && tokens && coef && rows > 0 && V > 0,
+    ICRL_REQUIRE(probs && dlogits && tokens && rows > 0 && V > 0,
                  "icrl_policy_dlogits: null pointer or empty shape");
     hipLaunchKernelGGL(policy_dlogits_kernel, dim3(grid_for((int64_t)rows * V, 256)), dim3(256), 0,
                        as_stream(stream), probs, dlogits, rows, V, tokens, token_stride, coef);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_scale_rows(const float* x, int64_t ldx, const float* coef, float* out, int64_t ldo, int rows,
+                               int cols, icrl_stream_t stream) {
+    ICRL_REQUIRE(x && coef && out && rows > 0 && cols > 0, "icrl_scale_rows: null pointer or empty shape");
+    ICRL_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(out) % 16 == 0, "icrl_scale_rows: rows must be 16-byte aligned, cols %% 4 == 0");
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for((int64_t)rows * cols / 4, 256)), dim3(256), 0, as_stream(stream),
+                       x, ldx, coef, out, ldo, rows, cols / 4);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -271,7 +271,7 @@ class A2CEngine:
                 X=f32(t_steps, n, e), logits=f32(n, v), probs=f32(s, n, v), logp=f32(s, n), entropy=f32(s, n),
                 dlogp=f32(s * n), dlogits=f32(s, n, v),
                 dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
-                dX=f32(t_steps * n, e))
+                dX=f32(t_steps * n, e), Uvocab=f32(s * n, H), HsC=f32(s * n, H))
             ws["Cbuf"][0].zero_()
         if self.V is not None:
             ev = self.V["valrnn.caption_embedding.weight"].shape[1]
@@ -283,16 +283,20 @@ class A2CEngine:
                 dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H),
                 dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev))
         if self.R is not None:
+            if s > 1:   # the A2C step's per-word input projections (see _word_tables)
+                ws["table_r"] = f32(self.R["rewrnn.caption_embedding.weight"].shape[0], 3 * H)
+                if self.V is not None:
+                    ws["table_v"] = f32(self.V["valrnn.caption_embedding.weight"].shape[0], 4 * H)
             ws.update(
                 XPr=f32(l_cols * n, 3 * H), hr=f32(s, n, H), se=f32(s * n, 512), ve=f32(n, 512), rewards=f32(s * n),
                 sync_r=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev))
         # split-K partial slabs: up to 16 of a [4H,H] weight gradient, 8 of the vocabulary projection's,
         # 5 of an activation gradient
         scratch = max(16 * 4 * H * H, 8 * (self.vocab or 0) * H, 5 * l_cols * n * max(widths))
-        ws["scratch_main"], ws["scratch_side"] = f32(scratch), f32(scratch)
+        ws["scratch_main"], ws["scratch_side"], ws["scratch_check"] = f32(scratch), f32(scratch), f32(scratch)
         # fixed-order reductions (bias gradients, embedding gradients): the same bits on every run
         cs = max(2048 * 64 + max(self.vocab or 0, 4 * H), n * 512)
-        ws["cs_main"], ws["cs_side"] = f32(cs), f32(cs)
+        ws["cs_main"], ws["cs_side"], ws["cs_check"] = f32(cs), f32(cs), f32(cs)
         vmax = self._emb_vocab() if (self.P is not None or self.V is not None) else 1
         ws["emb_work"] = torch.zeros(hip.embedding_grad_work_ints(vmax, l_cols * n), dtype=torch.int32, device=dev)
         k = n if self.per_sample else self._segments_for(tv, tv)
@@ -686,11 +690,18 @@ class A2CEngine:
             hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
             ev_feat = torch.cuda.Event()
             ev_feat.record(side)
+            self._word_tables(ws)
+            ev_tables = torch.cuda.Event()
+            ev_tables.record(side)
         self._rollout(ws, features, n, p0, s, uniforms, mode)
         self._mark("rollout_done")
         main.wait_event(ev_feat)
+        main.wait_event(ev_tables)
+        ws["policy_early"] = False
         if backward and mode != hip.GREEDY:
             self._order_tokens(ws, n, (p0 - 1 + s) * n, main, side)
+            if self.concurrent:
+                self._policy_backward_early(ws, n, p0, s, main, self._check_stream())
         last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
@@ -785,6 +796,36 @@ class A2CEngine:
         return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pv, pb), pr, status_host, full_calls=fc)
 
+    def _word_tables(self, ws):
+        """The chains' input projections for every WORD: table[w] = W_ih emb[w] + b (the value LSTM's with both
+        biases, the reward GRU's with b_ih).  They depend on the parameters only, so they are formed beside the
+        rollout; once the tokens exist a position's projection is a row gather - row by row the same sums as
+        the product over the gathered embeddings."""
+        V, R = self.V, self.R
+        hip.gemm(V["valrnn.caption_embedding.weight"], V["valrnn.lstm.weight_ih_l0"], ws["table_v"],
+                 bias=V["valrnn.lstm.bias_ih_l0"], bias2=V["valrnn.lstm.bias_hh_l0"])
+        hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["table_r"],
+                 bias=R["rewrnn.gru.bias_ih_l0"])
+
+    def _policy_backward_early(self, ws, n, p0, s, main, stream):
+        """The part of the policy network's backward pass that needs no loss: d logits up to the per-row
+        coefficient dLoss/dlog_prob, G0 = onehot(token) - softmax, and their product with the vocabulary matrix
+        U = G0 . W (what flows into the LSTM outputs is coef * U, row by row).  On `stream`, beside the chains."""
+        P = self.P
+        tok_flat = ws["tokT"].view(-1)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev)
+            G0 = ws["dlogits"].view(s * n, self.vocab)
+            hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G0, tok_flat[p0 * n:], 1, None)
+            hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ws["scratch_check"], b_kmajor=True, shared=True,
+                          dtype=self.pd)
+            done = torch.cuda.Event()
+            done.record(stream)
+            self._mark("check:policy_early_done")
+        ws["policy_early"], ws["ev_early"] = True, done
+
     def _order_tokens(self, ws, n, rows, main, side):
         """The rows of the token matrix listed by token (what the reproducible embedding gradients sum by): it
         needs the tokens only, and both trainable embedding tables are looked up with the same ones, so it is
@@ -851,8 +892,7 @@ class A2CEngine:
         ev_tok.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ev_tok)
-            hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["XPr"],
-                     a_rows=tok_flat[:l_cols * n], bias=R["rewrnn.gru.bias_ih_l0"])
+            hip.gather_rows(ws["table_r"], tok_flat, 1, l_cols * n, ws["XPr"])
             if pair:
                 ev_xpr = torch.cuda.Event()
                 ev_xpr.record(side)
@@ -869,9 +909,7 @@ class A2CEngine:
                 self._reward_head(ws, features, n, s, side, visual_done=True)
                 ev_rew = torch.cuda.Event()
                 ev_rew.record(side)
-        hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
-        hip.gemm(ws["Xv"], V["valrnn.lstm.weight_ih_l0"], ws["XPv"], bias=V["valrnn.lstm.bias_ih_l0"],
-                 bias2=V["valrnn.lstm.bias_hh_l0"])
+        hip.gather_rows(ws["table_v"], tok_flat, 1, lv * n, ws["XPv"])
         if pair:
             main.wait_event(ev_xpr)
         if rows:
@@ -1021,6 +1059,8 @@ class A2CEngine:
             else:
                 dgsum = ws["dGsum"]
                 hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
+            if ev_loss is not None:   # the A2C step took its input projections from the per-word table: gather x now
+                hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
             hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
             hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_side"])
             gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
@@ -1046,19 +1086,44 @@ class A2CEngine:
         main.wait_event(ev_side)
 
     def _policy_backward(self, ws, features, n, p0, s):
+        """Backward of the policy network from ws["dlogp"] = dLoss/dlog_prob (one coefficient per (step, row)).
+        d logits = coef * G0 with G0 = onehot - softmax, so the coefficient is applied to small matrices instead
+        of the [rows, V] one: what flows into the LSTM outputs is coef * (G0 . W) (G0 . W formed before the loss
+        when _policy_backward_early ran), the vocabulary matrix's gradient is G0^T . (coef * Hs) and its bias
+        gradient sum_r coef[r] G0[r, :].  The two vocabulary-sized gradients run on the third stream beside the
+        LSTM's backward-through-time."""
         P, gP = self.P, self.gP
         t_steps = p0 - 1 + s
-        tok_flat = ws["tokT"].view(-1)
-        G = ws["dlogits"].view(s * n, self.vocab)
-        hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G, tok_flat[p0 * n:], 1, ws["dlogp"])
+        coef = ws["dlogp"]
+        G0 = ws["dlogits"].view(s * n, self.vocab)
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
         ss = ws["scratch_side"]
-        hip.gemm_auto(G, Hs, gP["linear2vocab.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
-        hip.colsum(G, gP["linear2vocab.bias"], scratch=ws["cs_side"])
+        cur = torch.cuda.current_stream()
+        if ws.get("policy_early"):
+            cur.wait_event(ws["ev_early"])
+        else:
+            tok_flat = ws["tokT"].view(-1)
+            hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G0, tok_flat[p0 * n:], 1, None)
+            hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ss, b_kmajor=True, shared=True, dtype=self.pd)
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
-        hip.gemm_auto(G, P["linear2vocab.weight"], dHall[p0 - 1:].view(s * n, H), ss, b_kmajor=True, shared=True, dtype=self.pd)
+        hip.scale_rows(ws["Uvocab"], coef, dHall[p0 - 1:].view(s * n, H))
+        hip.scale_rows(Hs, coef, ws["HsC"])
+        # the vocabulary matrix's gradients: beside the rest when a third stream exists
+        other = self._check_stream() if (self.concurrent and ws.get("policy_early")) else cur
+        ev_scaled = torch.cuda.Event()
+        ev_scaled.record(cur)
+        with torch.cuda.stream(other):
+            other.wait_event(ev_scaled)
+            sc, cs = (ws["scratch_check"], ws["cs_check"]) if other is not cur else (ss, ws["cs_side"])
+            hip.gemm_auto(G0, ws["HsC"], gP["linear2vocab.weight"], sc, a_kmajor=True, b_kmajor=True, shared=True,
+                          dtype=self.pd)
+            hip.colsum(G0, gP["linear2vocab.bias"], scratch=cs, row_scale=coef)
+            ev_vocab = torch.cuda.Event()
+            ev_vocab.record(other)
+            if other is not cur:
+                self._mark("check:vocab_grads_done")
         dgp = ws["dgp"]
         dc = [ws["dc0"], ws["dc1"]]
         for k in range(t_steps - 1, -1, -1):
@@ -1080,3 +1145,4 @@ class A2CEngine:
             hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
         hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])
+        cur.wait_event(ev_vocab)

@@ -47,7 +47,8 @@ SIGNATURES = {
     "icrl_lstm_chain_bwd_seg": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 4),
     "icrl_gather_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
     "icrl_scatter_add_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
-    "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "icrl_colsum": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "icrl_scale_rows": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "icrl_colsum_scratch_floats": (c_i64, [c_int, c_int]),
     "icrl_embedding_grad_work_ints": (c_i64, [c_int, c_int]),
     "icrl_token_order": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
@@ -232,14 +233,26 @@ def scatter_add_rows(grad_table, idx, idx_stride, rows, rows_in):
                                         _ptr(_f32c(rows_in)), _stream()), "icrl_scatter_add_rows")
 
 
-def colsum(x, out, accumulate=False, rows=None, scratch=None):
-    """out[c] (+)= sum_r x[r, c].  scratch: a float32 buffer of at least colsum_scratch_floats(rows, cols); with
-    it the result is reproducible bit for bit (fixed summation order), without it float atomics are used."""
+def colsum(x, out, accumulate=False, rows=None, scratch=None, row_scale=None):
+    """out[c] (+)= sum_r row_scale[r] * x[r, c] (row_scale None = ones).  scratch: a float32 buffer of at least
+    colsum_scratch_floats(rows, cols); with it the result is reproducible bit for bit (fixed summation order),
+    without it float atomics are used."""
     rows = x.shape[0] if rows is None else rows
     if scratch is not None:
         assert scratch.dtype == torch.float32 and scratch.numel() >= colsum_scratch_floats(rows, x.shape[1])
-    _check(load().icrl_colsum(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(out), int(accumulate), _ptr(scratch),
-                              _stream()), "icrl_colsum")
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.is_contiguous() and row_scale.numel() >= rows
+    _check(load().icrl_colsum(_ptr(x), x.stride(0), rows, x.shape[1], _ptr(out), int(accumulate), _ptr(row_scale),
+                              _ptr(scratch), _stream()), "icrl_colsum")
+    return out
+
+
+def scale_rows(x, coef, out):
+    """out[r, :] = coef[r] * x[r, :] for 2-D x / out whose rows are contiguous."""
+    rows, cols = x.shape
+    assert out.shape == x.shape and x.stride(1) == 1 and out.stride(1) == 1 and coef.numel() >= rows
+    _check(load().icrl_scale_rows(_ptr(x), x.stride(0), _ptr(_f32c(coef)), _ptr(out), out.stride(0), rows, cols,
+                                  _stream()), "icrl_scale_rows")
     return out
 
 
@@ -322,9 +335,10 @@ def topk_rows(logits, k):
 
 
 def policy_dlogits(probs, dlogits, tokens, token_stride, coef):
+    """dlogits[r, k] = coef[r] * ((k == tokens[r]) - probs[r, k]); coef None = ones."""
     rows, v = probs.shape
     _check(load().icrl_policy_dlogits(_ptr(_f32c(probs)), _ptr(_f32c(dlogits)), rows, v, _ptr(tokens), token_stride,
-                                      _ptr(_f32c(coef)), _stream()), "icrl_policy_dlogits")
+                                      _ptr(None if coef is None else _f32c(coef)), _stream()), "icrl_policy_dlogits")
 
 
 def chain_sync_bytes():

@@ -102,12 +102,17 @@ int icrl_token_order(const int64_t* idx, int64_t idx_stride, int rows, int vocab
 int icrl_embedding_grad(float* grad_table, int vocab, int width, const float* rows_in, const int32_t* work,
                         icrl_stream_t stream);
 
-/* out[n] (+)= sum_r x[r, n]   (bias gradients).  scratch (may be NULL): icrl_colsum_scratch_floats(rows, cols)
- * floats; with it the row blocks' partial sums are added in a fixed order (reproducible bit for bit), without
- * it by float atomics. */
+/* out[n] (+)= sum_r row_scale[r] * x[r, n]   (bias gradients; row_scale may be NULL = ones).  scratch (may be
+ * NULL): icrl_colsum_scratch_floats(rows, cols) floats; with it the row blocks' partial sums are added in a
+ * fixed order (reproducible bit for bit), without it by float atomics. */
 int64_t icrl_colsum_scratch_floats(int rows, int cols);
 int icrl_colsum(const float* x, int64_t ldx, int rows, int cols, float* out, int accumulate,
-                float* scratch, icrl_stream_t stream);
+                const float* row_scale, float* scratch, icrl_stream_t stream);
+
+/* out[r, :] = coef[r] * x[r, :]: the policy-gradient coefficient dLoss/dlog_prob applied to rows whose
+ * products with the vocabulary matrix were formed before the loss was known (cols % 4 == 0). */
+int icrl_scale_rows(const float* x, int64_t ldx, const float* coef, float* out, int64_t ldo, int rows, int cols,
+                    icrl_stream_t stream);
 
 /* ---- batched LSTM cell (policy network, models.py:80) -----------------------
  * gates_pre[N,4H] holds x*W_ih^T + h*W_hh^T + b_ih + b_hh, PyTorch order i,f,g,o.
@@ -160,7 +165,8 @@ int icrl_topk_rows(const float* logits, int64_t ld_logits, int N, int V, int k, 
                    int64_t* indices, icrl_stream_t stream);
 
 /* d logits for the policy-gradient term from the saved softmax (dlogits may alias probs):
- * g[r, k] = coef[r] * ((k == token[r]) - p[r, k]),  coef = dLoss/dlog_prob. */
+ * g[r, k] = coef[r] * ((k == token[r]) - p[r, k]),  coef = dLoss/dlog_prob; coef NULL = ones (the
+ * coefficient is then applied later, by icrl_scale_rows / icrl_colsum's row_scale). */
 int icrl_policy_dlogits(const float* probs, float* dlogits, int rows, int V, const int64_t* tokens,
                         int64_t token_stride, const float* coef, icrl_stream_t stream);
 
