@@ -953,6 +953,9 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
 __global__ __launch_bounds__(256, 2) void seg_fwd_pair_persist(ChainArgs v, ChainArgs r, unsigned* abort_w, int per_chain,
                                                                int only) {
     __shared__ __attribute__((aligned(16))) float lds[2 * PBUF];
+    // every step of a chain waits for the step before it: its waves go first wherever another kernel's waves
+    // share their SIMD (products of another stream, whose work has no such chain of waits)
+    __builtin_amdgcn_s_setprio(3);
     const int id = blockIdx.x % per_chain;
     if (only == 1 || (only == 0 && (int)blockIdx.x < per_chain)) persist_chain<4>(v, id % 16, id / 16, abort_w, lds);
     else persist_chain<3>(r, id % 16, id / 16, abort_w, lds);
@@ -1005,6 +1008,7 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     constexpr int LDS_FLOATS = 21 * 1024;
     static_assert(LDS_FLOATS >= 2 * PBUF2 && TILE2 >= 32 * PLD, "stage buffers, partial tile inside a wave's stage tile");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __builtin_amdgcn_s_setprio(3);   // as in the forward launch: the chain's waves before another stream's
     const Geom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;

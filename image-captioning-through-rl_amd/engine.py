@@ -171,6 +171,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
+                 frozen_reward=False,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1536, 2048), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -192,6 +193,9 @@ class A2CEngine:
         # float32 sums.  The chains, heads, softmax / sampler and every reduction stay float32 either way.
         assert policy_dtype in ("f32", "bf16")
         self.pd = policy_dtype
+        # frozen_reward: the caller promises not to write to the reward network's parameters between steps
+        # without calling parameters_changed(); what depends on them alone is then computed once
+        self.frozen_reward, self._param_epoch = bool(frozen_reward), 0
         self.max_segments = int(max_segments)
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
         self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
@@ -234,6 +238,11 @@ class A2CEngine:
         for group in groups:
             for k, t in group.items():
                 assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), k
+
+    def parameters_changed(self):
+        """Tell the engine that parameters it was told are frozen have been written to (a checkpoint was
+        loaded, say): everything cached from them is rebuilt on the next step."""
+        self._param_epoch += 1
 
     # ------------------------------------------------------------------ workspaces
     MIN_REPLAY = 128      # shortest replay, in positions, that is ever left out
@@ -441,34 +450,43 @@ class A2CEngine:
     def _rollout(self, ws, features, n, p0, s, uniforms, mode):
         """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
         from column to column, only the newest position projected to the vocabulary and sampled (or
-        arg-maxed, or scored against the forced token)."""
+        arg-maxed, or scored against the forced token).  (Cutting the rows into two groups issued
+        alternately on two streams was measured and gains nothing: 2.30-2.37 ms against 2.26-2.33.)"""
         P = self.P
         t_steps = p0 - 1 + s
-        tokT = ws["tokT"]
-        Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
+        Hb = ws["Hbuf"]
         # h0 = cnn2linear(features): a 64-tile output with a long k, first on the step's critical path; k is
         # split over workgroups (partial slabs summed on top of the bias)
         Hb[0].copy_(P["cnn2linear.bias"].expand_as(Hb[0]))
         hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True, dtype=self.pd)
         fused_step = self.E % 64 == 0 and self.pd == "f32"
         for k in range(t_steps):
-            if fused_step:  # gather + both gate products + cell in one launch
-                hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k], P["lstm.weight_ih_l0"],
-                                     P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k], Cb[k],
-                                     gates[k], Cb[k + 1], Hb[k + 1], X[k])
-            else:
-                hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
-                hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"],
-                         bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
-                hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True, dtype=self.pd)
-                hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
-            if k >= p0 - 1:
-                st = k - (p0 - 1)
-                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], ws["logits"], bias=P["linear2vocab.bias"], dtype=self.pd)
-                hip.sample_tokens(ws["logits"], mode, tokT[k + 1], 1,
-                                  uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n],
-                                  log_prob=ws["logp"][st], probs=ws["probs"][st] if mode != hip.GREEDY else None,
-                                  entropy=ws["entropy"][st] if (self.want_entropy and mode != hip.GREEDY) else None)
+            self._rollout_step(ws, k, 0, n, n, p0, uniforms, mode, fused_step)
+
+    def _rollout_step(self, ws, k, lo, hi, n, p0, uniforms, mode, fused_step):
+        """Step k of the rollout for rows [lo, hi) on the current stream."""
+        P = self.P
+        tokT = ws["tokT"]
+        Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
+        r = slice(lo, hi)
+        if fused_step:  # gather + both gate products + cell in one launch
+            hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k][r], P["lstm.weight_ih_l0"],
+                                 P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k][r], Cb[k][r],
+                                 gates[k][r], Cb[k + 1][r], Hb[k + 1][r], X[k][r])
+        else:
+            hip.gather_rows(P["caption_embedding.weight"], tokT[k][r], 1, hi - lo, X[k][r])
+            hip.gemm(X[k][r], P["lstm.weight_ih_l0"], gates[k][r], bias=P["lstm.bias_ih_l0"],
+                     bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
+            hip.gemm(Hb[k][r], P["lstm.weight_hh_l0"], gates[k][r], accumulate=True, dtype=self.pd)
+            hip.lstm_cell_fwd(gates[k][r], Cb[k][r], Cb[k + 1][r], Hb[k + 1][r])
+        if k >= p0 - 1:
+            st = k - (p0 - 1)
+            logits = ws["logits"][r]
+            hip.gemm(Hb[k + 1][r], P["linear2vocab.weight"], logits, bias=P["linear2vocab.bias"], dtype=self.pd)
+            hip.sample_tokens(logits, mode, tokT[k + 1][r], 1,
+                              uniforms=None if uniforms is None else uniforms[st * n + lo:st * n + hi],
+                              log_prob=ws["logp"][st][r], probs=ws["probs"][st][r] if mode != hip.GREEDY else None,
+                              entropy=ws["entropy"][st][r] if (self.want_entropy and mode != hip.GREEDY) else None)
 
     # ------------------------------------------------------------------ pre-training steps
     def policy_ce_step(self, features, captions, valid_steps, row_weight):
@@ -690,9 +708,12 @@ class A2CEngine:
             hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
             ev_feat = torch.cuda.Event()
             ev_feat.record(side)
+        tables_on = self._check_stream() if self.concurrent else main
+        with torch.cuda.stream(tables_on):
+            tables_on.wait_event(ev_start)
             self._word_tables(ws)
             ev_tables = torch.cuda.Event()
-            ev_tables.record(side)
+            ev_tables.record(tables_on)
         self._rollout(ws, features, n, p0, s, uniforms, mode)
         self._mark("rollout_done")
         main.wait_event(ev_feat)
@@ -804,8 +825,12 @@ class A2CEngine:
         V, R = self.V, self.R
         hip.gemm(V["valrnn.caption_embedding.weight"], V["valrnn.lstm.weight_ih_l0"], ws["table_v"],
                  bias=V["valrnn.lstm.bias_ih_l0"], bias2=V["valrnn.lstm.bias_hh_l0"])
-        hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["table_r"],
-                 bias=R["rewrnn.gru.bias_ih_l0"])
+        # a reward network declared frozen (it is, during A2C training: trainers.py:372-373) keeps its table
+        # until parameters_changed() is called
+        if not (self.frozen_reward and ws.get("table_r_epoch") == self._param_epoch):
+            hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["table_r"],
+                     bias=R["rewrnn.gru.bias_ih_l0"])
+            ws["table_r_epoch"] = self._param_epoch
 
     def _policy_backward_early(self, ws, n, p0, s, main, stream):
         """The part of the policy network's backward pass that needs no loss: d logits up to the per-row

@@ -98,12 +98,19 @@ class _Timed:
         if PROFILE is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream())
+            self.e0.record(_torch_stream())
 
     def __exit__(self, *exc):
         if PROFILE is not None:
-            self.e1.record(torch.cuda.current_stream())
+            self.e1.record(_torch_stream())
             PROFILE.append((self.kind, self.work, self.e0, self.e1, self.nbytes, self.steps, self.flops))
+
+
+def _torch_stream():
+    """The stream launches go to, as a torch object (for event records)."""
+    if STREAM is None:
+        return torch.cuda.current_stream()
+    return torch.cuda.ExternalStream(STREAM)
 
 
 def chain_positions(n, p0, n_calls, full_calls=0):
@@ -152,8 +159,14 @@ def _ptr(t):
     return t.data_ptr()
 
 
+# When set (an int: a HIP stream handle), every launch goes to that stream instead of PyTorch's current one.
+# Cheaper than entering a torch.cuda.stream() context per launch group for code that alternates between
+# streams hundreds of times per minibatch.
+STREAM = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream().cuda_stream if STREAM is None else STREAM
 
 
 def _check(rc, what):

@@ -195,6 +195,9 @@ def build_engine(a2c_network, reward_network, **engine_options):
     per_sample=True get the engine's per-image recurrent state too, unless chain_semantics is given."""
     if getattr(a2c_network.value_network.valrnn, "per_sample", False):
         engine_options.setdefault("chain_semantics", "per_sample")
+    # a reward network without trainable parameters (trainers.py:372-373 freezes it) is not written to between
+    # minibatches; whoever loads new weights into it afterwards calls engine.parameters_changed()
+    engine_options.setdefault("frozen_reward", not any(p.requires_grad for p in reward_network.parameters()))
     return A2CEngine(_params_of(a2c_network.policy_network), _params_of(a2c_network.value_network),
                      _params_of(reward_network), _grads_of(a2c_network.policy_network),
                      _grads_of(a2c_network.value_network), **engine_options)
