@@ -142,6 +142,10 @@ def main():
                          "workload: a different computation, reported under its own workload name)")
     ap.add_argument("--no-collapse", action="store_true", help="walk every call of the chains in full")
     args = ap.parse_args()
+    watchdog = float(os.environ.get("ICRL_BENCH_WATCHDOG", "0"))
+    if watchdog > 0:   # a run that is still going after this many seconds prints every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(watchdog, exit=True)
 
     syn = importlib.import_module(PKG + ".synthetic")
     hip = importlib.import_module(PKG + ".hipabi")
@@ -209,6 +213,8 @@ def main():
     timed_fallbacks = engine.fallbacks - fallbacks_before
     final_plans = plans_of(res, engine)
     last_loss = float(res.scalars[0])
+    in_step = ddp.same_on_all_ranks(flat.flat)   # every rank applied the same Adam updates to the same parameters
+    gave_up = int(ddp.max_over_ranks(engine.launch_timeouts, dev))
 
     # ---- steady state: the networks keep training, the value LSTM's memory (and with it the warm-up) moves
     soak = None
@@ -310,6 +316,8 @@ def main():
                                       ", data-parallel over the GPUs" if world > 1 else ""),
                        "global_batch": world * n, "parallelism": "dp%d" % world,
                        "backend": args.backend if world > 1 else None},
+            "parameters_identical_across_ranks": in_step if world > 1 else None,
+            "launches_that_gave_up_waiting": gave_up,
             "soak": soak,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,

@@ -120,6 +120,24 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def same_on_all_ranks(flat):
+    """True when every rank holds bit-identical contents of the float32 buffer `flat`: three 64-bit integer
+    checksums of its bit patterns (sum, sum of squares of the low halves, position-weighted sum), MIN and
+    MAX over ranks equal."""
+    if not _active():
+        return True
+    bits = flat.detach().contiguous().view(torch.int32).to(torch.int64)
+    weights = torch.arange(bits.numel(), dtype=torch.int64, device=bits.device) % 65521 + 1
+    low = bits & 0xFFFF
+    sums = torch.stack([bits.sum(), (low * low).sum(), (bits * weights).sum()])
+    lo, hi = sums.clone(), sums.clone()
+    if dist.get_backend() != "nccl":
+        lo, hi = lo.cpu(), hi.cpu()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 

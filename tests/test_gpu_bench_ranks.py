@@ -1,0 +1,51 @@
+"""bench.py launched the way the multi-GPU driver launches it, with two ranks that share ONE GPU and exchange
+their gradients through gloo: the barrier, the max-over-ranks timing, the rank-0 print and the per-rank shards
+of the N > 1 path, run for real.  Needs an MI355X.
+
+The batch stays small on purpose: two ranks that share one GPU AND run in lock step launch their 256-workgroup
+persistent chain kernels at the same instant, each holding part of the CUs while it waits for the rest, and a
+batch-512 step then takes seconds (two processes that are NOT in lock step share the card at 2 x 9 ms a step).
+One process per GPU, the only supported layout, has no such neighbour."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+_launches = []
+
+
+def _launch(ranks, extra, timeout=240):
+    _launches.append(1)
+    port = 29700 + (os.getpid() * 7 + len(_launches) * 13) % 250   # a fresh port per launch
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(ranks), "--backend", "gloo", "--no-cpu-baseline"] + extra
+    # a rank still running after 120 s prints its threads' stacks and exits, so a hang names its place
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICRL_BENCH_WATCHDOG="120")
+    done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0: %r" % done.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_prints_one_line_and_keeps_the_ranks_in_step():
+    n = 64
+    out = _launch(2, ["--steps", "3", "--warmup", "2", "--soak", "6", "--batch", str(n), "--vocab", "1000",
+                      "--fdim", "512", "--caplen", "12"])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2
+    assert out["config"]["global_batch"] == 2 * n and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["parameters_identical_across_ranks"] is True
+    assert out["launches_that_gave_up_waiting"] == 0
+    assert out["value"] == pytest.approx(2 * n * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)
+    assert out["soak"]["minibatches"] == 6 and out["soak"]["images_per_s"] > 0
+    assert "cpu_baseline" not in out   # rank 0 at N = 1 only
+    assert out["last_loss"] == out["last_loss"]   # not NaN
