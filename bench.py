@@ -95,10 +95,19 @@ def cpu_baseline(syn, params, vocab, caplen, fdim, sample_batch, repeats):
 
 
 def git_sha():
+    """HEAD of this tree; where the tree travelled without its history, the sha the library was built at
+    (csrc/BUILD_SHA, written by __graft_entry__.build())."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                             timeout=5).stdout.strip()
+        if sha:
+            return sha
     except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        with open(os.path.join(ROOT, PKG, "csrc", "BUILD_SHA")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 

@@ -14,9 +14,20 @@ import glob
 import json
 import os
 import re
+import subprocess
 import sys
 
 SIMDS = 256 * 4
+
+
+def git_sha():
+    """HEAD of the tree the summary is written in (the runs are made from that same tree)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        return None
 
 
 def short(name):
@@ -37,7 +48,7 @@ def main(directory, out_path):
         acc[0] += 1
         acc[1] += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         acc[2] += d.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
-    out = {"_note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; utilisation = busy cycles / "
+    out = {"_git_sha": git_sha(), "_note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; utilisation = busy cycles / "
                     "(dispatch cycles * 1024 SIMDs); kernels run one at a time under counter collection"}
     for name, (n, busy, cycles) in table.items():
         if busy > 0:
@@ -45,7 +56,7 @@ def main(directory, out_path):
                          "mfma_utilisation": busy / (cycles * SIMDS) if cycles else None}
     with open(out_path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    for name, row in sorted(((k, v) for k, v in out.items() if k != "_note"), key=lambda kv: -kv[1]["launches"] * kv[1]["cycles_per_launch"]):
+    for name, row in sorted(((k, v) for k, v in out.items() if not k.startswith("_")), key=lambda kv: -kv[1]["launches"] * kv[1]["cycles_per_launch"]):
         print("%-28s n=%5d  cycles/launch %.3e  MFMA utilisation %.1f %%" % (name, row["launches"], row["cycles_per_launch"],
                                                                          100 * row["mfma_utilisation"]))
 

@@ -13,7 +13,18 @@ import glob
 import json
 import os
 import re
+import subprocess
 import sys
+
+
+def git_sha():
+    """HEAD of the tree the summary is written in (the runs are made from that same tree)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        return None
 
 
 def short(name):
@@ -44,7 +55,7 @@ def main(fetch_dir, write_dir, out_path):
                        "fetch_bytes_per_launch": 2.0 * bf / nf if nf else 0.0,
                        "write_bytes_per_launch": bw / nw if nw else 0.0}
     with open(out_path, "w") as f:
-        json.dump({"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+        json.dump({"_git_sha": git_sha(), "_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                             "(separate passes; FETCH_SIZE doubled for gfx950)", **table}, f, indent=1, sort_keys=True)
     for name, row in sorted(table.items(), key=lambda kv: -kv[1]["launches"] * (kv[1]["fetch_bytes_per_launch"] + kv[1]["write_bytes_per_launch"])):
         print(f"{name:32s} n={row['launches']:6d} fetch/launch={row['fetch_bytes_per_launch'] / 1e6:9.2f} MB "
