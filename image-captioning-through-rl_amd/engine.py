@@ -133,8 +133,19 @@ class _WarmupLadder:
         gain = self.warmups[self.first] - self.warmups[self.first - 1]
         return 6 if gain >= 64 else 24 if gain >= 32 else 64
 
+    EXACT_RETRY = 16   # minibatches on the exact kernels before the longest warm-up is tried again
+
     def accepted(self, idx, checks, last):
-        if idx != self.first or not checks:
+        if idx != self.first:
+            return
+        if not checks:
+            # the exact kernels ran: nothing was measured.  They cost many times the longest rung, so that rung
+            # is tried again now and then (a failed try lengthens the wait like any failed probe)
+            if idx >= len(self.warmups) > 0:
+                self.cooldown = max(0, self.cooldown - 1)
+                self.calm += 1
+                if self.calm >= self.EXACT_RETRY and self.cooldown == 0:
+                    self.first, self.calm, self.probing = len(self.warmups) - 1, 0, True
             return
         worst = max(e / t if t > 0 else float("inf") for e, t in checks)
         if self.prev is not None and self.prev[0] == idx and self.prev[1] > 0.1:
@@ -173,7 +184,7 @@ class A2CEngine:
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
                  frozen_reward=False,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
-                          1536, 2048), first_warmup=96):
+                          1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
         parameter storage).  *_grads: same keys -> gradient tensors to fill; parameters
         missing from the grads dicts (e.g. frozen pretrained embeddings) get no gradient."""
@@ -356,10 +367,12 @@ class A2CEngine:
         return plans + [("exact",)]
 
     def _replay_steps(self, w_fwd):
-        """Steps of a left-out replay that the check walks: a quarter more than the longest forward warm-up
-        in use (the seams say that a zero state is forgotten within one warm-up).  The check measures, so
-        any length is safe; a short one only risks asking for more calls in full than needed."""
-        return max(self.MIN_REPLAY, w_fwd + w_fwd // 4)
+        """Steps of a left-out replay that the check walks: the longest forward warm-up in use (the seams say
+        that within it even a zero state is forgotten; the replay starts from a state of the trajectory).  The
+        check measures, so any length is safe; a short one only risks asking for more calls in full than
+        needed.  It runs after the forward chains and, at long warm-ups, longer than the backward pass beside
+        it, so it is not made longer than that."""
+        return max(self.MIN_REPLAY, w_fwd)
 
     def _full_calls(self, n, p0, s, w_fwd, w_bwd):
         """How many calls the chains walk in full: the fewest for which every replay left out is at least
@@ -743,6 +756,7 @@ class A2CEngine:
                 self._backward(ws, features, n, p0, s, fc, main, side, pb)
             self._mark("backward_done")
             seg_v, seg_r = pv[0] == "segmented", pr[0] == "segmented"
+            checks_v, checks_r = [], []
             if seg_v or seg_r:
                 ev_seam.synchronize()
                 seam = ws["seam_host"].tolist()
@@ -775,9 +789,11 @@ class A2CEngine:
                     continue
             else:
                 self.last_replay = (fc, 0, 0.0, 0.0)
-            if seg_v or seg_r:
-                self._ladder_fv.accepted(fv, checks_v, last)
-                self._ladder_fr.accepted(fr, checks_r, last)
+            if not self.per_sample and ws["segments"]:
+                self._ladder_fv.accepted(fv, checks_v if seg_v else [], last)
+                self._ladder_fr.accepted(fr, checks_r if seg_r else [], last)
+                if with_bwd and pb[0] == "exact":
+                    self._ladder_bwd.accepted(bi, [], last)
             self.last_seam = ws["seam_host"].tolist()[:4] + [0.0, 0.0]
             if with_bwd and self.on_policy_grads is not None and self._ev_policy is not None:
                 # the forward pass stands, so the policy gradients being computed now are final

@@ -1,6 +1,6 @@
 """Time the segment-parallel chain kernels alone and side by side (us per step launch).
 
-    python tools/chain_bench.py [segments] [warmup]
+    python tools/chain_bench.py [segments] [warmup] [full_calls: 0 = every call in full, 1 = replays left out]
 """
 import importlib
 import os
@@ -15,9 +15,10 @@ H = 512
 n, p0, s = 512, 1, 19
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+FC = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = "cuda"
-tv = n * sum(p0 + k for k in range(s))
-tr = n * sum(p0 + 1 + k for k in range(s))
+tv = hip.chain_positions(n, p0, s, FC)
+tr = hip.chain_positions(n, p0 + 1, s, FC)
 g = torch.Generator(device="cpu").manual_seed(0)
 
 
@@ -39,15 +40,15 @@ side = torch.cuda.Stream()
 
 
 def fwd_v():
-    hip.lstm_chain_fwd_seg(xp_v, w_v, n, p0, s, K, W, hv, saved, work_v, seam[0:2])
+    hip.lstm_chain_fwd_seg(xp_v, w_v, n, p0, s, K, W, hv, saved, work_v, seam[0:2], full_calls=FC)
 
 
 def fwd_r():
-    hip.gru_chain_fwd_seg(xp_r, w_r, b_r, n, p0 + 1, s, K, W, hr, work_r, seam[2:4])
+    hip.gru_chain_fwd_seg(xp_r, w_r, b_r, n, p0 + 1, s, K, W, hr, work_r, seam[2:4], full_calls=FC)
 
 
 def bwd_v():
-    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv, work_v, seam[4:6])
+    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv, work_v, seam[4:6], full_calls=FC)
 
 
 def both():
@@ -68,7 +69,7 @@ seam2 = torch.zeros(6, device=dev)
 
 def pair():
     hip.chain_pair_fwd_seg(xp_v, w_v, xp_r, w_r, b_r, n, p0, p0 + 1, s, K, W, hv2, saved2, hr2, work_v, work_r,
-                           seam2[0:1], seam2[2:3])
+                           seam2[0:1], seam2[2:3], full_calls=FC)
 
 
 def timeit(name, fn, steps, reps=3):
@@ -84,7 +85,7 @@ def timeit(name, fn, steps, reps=3):
     print("%-28s %7.3f ms  %6.2f us/step (%d steps)" % (name, ms, 1e3 * ms / steps, steps), flush=True)
 
 
-print("segments %d warmup %d" % (K, W))
+print("segments %d warmup %d full_calls %d (%d / %d positions)" % (K, W, FC, tv, tr))
 timeit("lstm fwd alone", fwd_v, steps_v)
 timeit("gru fwd alone", fwd_r, steps_r)
 timeit("lstm+gru fwd, two streams", both, max(steps_v, steps_r))
@@ -104,17 +105,17 @@ if hip.chain_pair_supported(K):
     dgv2 = torch.empty_like(dgv)
     seam3 = torch.zeros(2, device=dev)
     timeit("lstm bwd persistent", lambda: hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv2, work_v, seam3,
-                                                                 persistent=True), steps_v + 1)
+                                                                 persistent=True, full_calls=FC), steps_v + 1)
     bwd_v(); torch.cuda.synchronize()
     print("bwd persistent == per-step:", torch.equal(dgv, dgv2), seam3.tolist(), float((dgv - dgv2).abs().max()))
 print("seam", seam.tolist())
 if hip.chain_pair_supported(K):
     dgv3 = torch.empty_like(dgv)
-    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv3, work_v, seam3, persistent=True)
+    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv3, work_v, seam3, persistent=True, full_calls=FC)
     torch.cuda.synchronize()
     print("persistent run-to-run equal:", torch.equal(dgv2, dgv3))
     dgv4 = torch.empty_like(dgv)
-    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv4, work_v, seam3)
+    hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv4, work_v, seam3, full_calls=FC)
     torch.cuda.synchronize()
     print("per-step run-to-run equal:", torch.equal(dgv, dgv4))
     d = (dgv - dgv2).abs()
