@@ -192,19 +192,61 @@ __global__ __launch_bounds__(1024) void emb_offsets(int* __restrict__ slice_coun
     }
 }
 
-__global__ __launch_bounds__(128) void emb_sum_rows(const float* __restrict__ rows_in, int width, const int* __restrict__ count,
+// Sum of rows_in[order[k]] over k in [lo, hi), added in that order; eight row loads in flight.
+__device__ __forceinline__ float4 emb_sum_range(const float* __restrict__ rows_in, int width, const int* __restrict__ order,
+                                                int lo, int hi, int c) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = lo;
+    for (; k + 8 <= hi; k += 8) {
+        int r[8];
+        float4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = order[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = reinterpret_cast<const float4*>(rows_in + (int64_t)r[u] * width)[c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += a[u].x; s.y += a[u].y; s.z += a[u].z; s.w += a[u].w; }
+    }
+    for (; k < hi; ++k) {
+        const float4 a = reinterpret_cast<const float4*>(rows_in + (int64_t)order[k] * width)[c];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    return s;
+}
+
+// One workgroup per token: grad[v] = sum of the token's rows.  Short lists (the usual case) are summed in
+// ascending row order by the first 128 lanes; a list of EMB_SPLIT_MIN rows or more (a caption's start or
+// padding token holds a row of every image) is cut into four consecutive quarters, one per group of 128
+// lanes, each summed in ascending order, and the quarters are added in order: a fixed order either way.
+constexpr int EMB_SPLIT_MIN = 32;
+__global__ __launch_bounds__(512) void emb_sum_rows(const float* __restrict__ rows_in, int width, const int* __restrict__ count,
                                                     const int* __restrict__ offset, const int* __restrict__ order,
                                                     float* __restrict__ grad) {
+    __shared__ float4 part[3][128];
     const int v = blockIdx.x;
     const int n = count[v], first = offset[v];
     const int w4 = width >> 2;
-    for (int c = threadIdx.x; c < w4; c += 128) {
+    const int col = threadIdx.x & 127, g = threadIdx.x >> 7;
+    if (n < EMB_SPLIT_MIN) {      // uniform over the workgroup
+        if (g != 0) return;
+        for (int c = col; c < w4; c += 128)
+            reinterpret_cast<float4*>(grad + (int64_t)v * width)[c] = emb_sum_range(rows_in, width, order, first, first + n, c);
+        return;
+    }
+    const int q = (n + 3) >> 2;
+    const int lo = first + min(n, g * q), hi = first + min(n, (g + 1) * q);
+    for (int base = 0; base < w4; base += 128) {
+        const int c = base + col;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < n; ++k) {
-            const float4 a = reinterpret_cast<const float4*>(rows_in + (int64_t)order[first + k] * width)[c];
-            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        if (c < w4) s = emb_sum_range(rows_in, width, order, lo, hi, c);
+        if (g != 0) part[g - 1][col] = s;
+        __syncthreads();
+        if (g == 0 && c < w4) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { const float4 a = part[p][col]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+            reinterpret_cast<float4*>(grad + (int64_t)v * width)[c] = s;
         }
-        reinterpret_cast<float4*>(grad + (int64_t)v * width)[c] = s;
+        __syncthreads();
     }
 }
 
@@ -660,7 +702,7 @@ extern "C" int icrl_embedding_grad(float* grad_table, int vocab, int width, cons
     ICRL_REQUIRE(grad_table && rows_in && work && vocab > 0, "icrl_embedding_grad: null pointer or empty shape");
     ICRL_REQUIRE(width % 4 == 0 && reinterpret_cast<uintptr_t>(grad_table) % 16 == 0 &&
                  reinterpret_cast<uintptr_t>(rows_in) % 16 == 0, "icrl_embedding_grad: width %% 4 and 16-byte alignment required");
-    hipLaunchKernelGGL(emb_sum_rows, dim3(vocab), dim3(128), 0, as_stream(stream), rows_in, width, work, work + vocab,
+    hipLaunchKernelGGL(emb_sum_rows, dim3(vocab), dim3(512), 0, as_stream(stream), rows_in, width, work, work + vocab,
                        work + 2 * (int64_t)vocab, grad_table);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;

@@ -876,6 +876,7 @@ class A2CEngine:
             return
         if side is main:
             hip.token_order(ws["tokT"].view(-1), 1, rows, self._emb_vocab(), ws["emb_work"])
+            ws["ev_order_done"] = None
             return
         # on the third stream (idle until the replay check), so that it delays neither the chains' input
         # products on the side stream nor the chains; the side stream picks the result up from there
@@ -887,7 +888,7 @@ class A2CEngine:
             hip.token_order(ws["tokT"].view(-1), 1, rows, self._emb_vocab(), ws["emb_work"])
             done = torch.cuda.Event()
             done.record(check)
-        ws["ev_order"] = done
+        ws["ev_order"] = ws["ev_order_done"] = done   # side stream (policy table) and main stream (value table) wait on it
 
     def _emb_vocab(self):
         sizes = {g[k].shape[0] for g, k in ((self.P, "caption_embedding.weight"), (self.V, "valrnn.caption_embedding.weight"))
@@ -1081,10 +1082,10 @@ class A2CEngine:
         self._mark("value_chain_bwd_done")
         ev_chain = torch.cuda.Event()
         ev_chain.record(main)
-        # ---- side stream: the policy network's BPTT beside the value chain, then the value network's
-        # input-side gradients once the chain is done
-        with torch.cuda.stream(side):
-            if ev_loss is not None:
+        # ---- side stream: the policy network's BPTT beside the value chain
+        ev_side = None
+        if ev_loss is not None:
+            with torch.cuda.stream(side):
                 side.wait_event(ev_loss)
                 self._mark("side:policy_bwd_start")
                 if ws.get("ev_order") is not None:
@@ -1093,38 +1094,40 @@ class A2CEngine:
                 self._mark("side:policy_bwd_done")
                 self._ev_policy = torch.cuda.Event()
                 self._ev_policy.record(side)
-            side.wait_event(ev_chain)
-            ss = ws["scratch_side"]
-            if fc == 1 and p0 == 1 and s > 1:
-                dgsum = dgv          # every column occurs once in the chain: nothing to sum over calls
-            else:
-                dgsum = ws["dGsum"]
-                hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
-            if ev_loss is not None:   # the A2C step took its input projections from the per-word table: gather x now
-                hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
-            hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True)
-            hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_side"])
-            gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
-            g_emb = gV.get("valrnn.caption_embedding.weight")
-            if g_emb is not None:
-                hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], ss, b_kmajor=True)
-                hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
-            self._mark("side:value_input_grads_done")
-            ev_side = torch.cuda.Event()
-            ev_side.record(side)
+                ev_side = self._ev_policy
 
         # ---- main stream: the recurrent weight gradient, sum over the positions of dgates (x) h_prev.  The
         # previous position's h is read in place from the kept activations (slot 5 of the position before,
         # a strided view); the chain's first position(s) had h_prev = 0 and drop out of the sum.
+        sm = ws["scratch_main"]
         back = n if plan[0] == "rows" else 1
         if tv > back:
             h_prev = saved.view(tv, 6 * H)[:tv - back, 5 * H:]
-            hip.gemm_auto(dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], ws["scratch_main"], a_kmajor=True,
-                          b_kmajor=True)
+            hip.gemm_auto(dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], sm, a_kmajor=True, b_kmajor=True)
         else:
             gV["valrnn.lstm.weight_hh_l0"].zero_()
         self._mark("value_wgrads_done")
-        main.wait_event(ev_side)
+        # ---- then the value network's input-side gradients (the policy network's backward pass outlasts the
+        # chain's on the side stream, so these follow the chain on this one)
+        if fc == 1 and p0 == 1 and s > 1:
+            dgsum = dgv          # every column occurs once in the chain: nothing to sum over calls
+        else:
+            dgsum = ws["dGsum"]
+            hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
+        if ev_loss is not None:   # the A2C step took its input projections from the per-word table: gather x now
+            hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
+        hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], sm, a_kmajor=True, b_kmajor=True)
+        hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_main"])
+        gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
+        g_emb = gV.get("valrnn.caption_embedding.weight")
+        if g_emb is not None:
+            if ws.get("ev_order_done") is not None:
+                main.wait_event(ws["ev_order_done"])
+            hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], sm, b_kmajor=True)
+            hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
+        self._mark("value_input_grads_done")
+        if ev_side is not None:
+            main.wait_event(ev_side)
 
     def _policy_backward(self, ws, features, n, p0, s):
         """Backward of the policy network from ws["dlogp"] = dLoss/dlog_prob (one coefficient per (step, row)).
