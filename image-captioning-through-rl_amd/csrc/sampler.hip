@@ -12,6 +12,8 @@
 namespace {
 using namespace icrl;
 
+constexpr int H = kHidden;
+
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -30,12 +32,26 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The policy LSTM's next cell update, run by the workgroup that has just fixed its row's token (pre == nullptr:
+// none).  pre[r] holds h . W_hh^T for the row's new state input (no bias), table[w] the input side of word w
+// (W_ih emb[w] + b_ih + b_hh); gates_out receives the activated i, f, g, o.
+struct NextCell {
+    const float* pre;
+    int64_t ld_pre;
+    const float* table;
+    float* gates_out;
+    const float* c_prev;
+    float* c_out;
+    float* h_out;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int64_t ld, int V,
                                                      const double* __restrict__ uniforms,
                                                      int64_t* __restrict__ tokens, int64_t token_stride,
                                                      float* __restrict__ log_prob, int64_t lp_stride,
-                                                     float* __restrict__ probs, float* __restrict__ entropy) {
+                                                     float* __restrict__ probs, float* __restrict__ entropy,
+                                                     NextCell cell) {
     extern __shared__ __attribute__((aligned(16))) float row[];  // V floats
     __shared__ float redf[4];
     __shared__ double redd[4];
@@ -186,6 +202,34 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const bool ok = token >= 0 && token < V;
         log_prob[r * lp_stride] = ok ? logf(row[token]) : NAN;
     }
+    if (cell.pre != nullptr && token >= 0 && token < V) {
+        // gates = h . W_hh^T + (W_ih x + b) for the token just fixed, then the cell (models.py:80): two units a lane
+        const float* pr = cell.pre + (int64_t)r * cell.ld_pre;
+        const float* tb = cell.table + (int64_t)token * (4 * H);
+        float* go_ = cell.gates_out + (int64_t)r * (4 * H);
+        for (int u = 2 * tid; u < H; u += 512) {
+            float2 g4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 a = *reinterpret_cast<const float2*>(pr + q * H + u);
+                const float2 b = *reinterpret_cast<const float2*>(tb + q * H + u);
+                g4[q] = make_float2(a.x + b.x, a.y + b.y);
+            }
+            const float2 cp = *reinterpret_cast<const float2*>(cell.c_prev + (int64_t)r * H + u);
+            float2 c, h;
+#define ICRL_NEXT_CELL(k)                                                   \
+    g4[0].k = sigmoidf_(g4[0].k); g4[1].k = sigmoidf_(g4[1].k);             \
+    g4[2].k = tanhf_(g4[2].k);    g4[3].k = sigmoidf_(g4[3].k);             \
+    c.k = g4[1].k * cp.k + g4[0].k * g4[2].k;                               \
+    h.k = g4[3].k * tanhf_(c.k);
+            ICRL_NEXT_CELL(x) ICRL_NEXT_CELL(y)
+#undef ICRL_NEXT_CELL
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float2*>(go_ + q * H + u) = g4[q];
+            *reinterpret_cast<float2*>(cell.c_out + (int64_t)r * H + u) = c;
+            *reinterpret_cast<float2*>(cell.h_out + (int64_t)r * H + u) = h;
+        }
+    }
 }
 
 
@@ -229,6 +273,35 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ log
 
 }  // namespace
 
+namespace {
+int launch_sampler(const float* logits, int64_t ld_logits, int N, int V, int mode, const double* uniforms,
+                   int64_t* tokens_out, int64_t token_stride, float* log_prob, int64_t log_prob_stride, float* probs,
+                   float* entropy, const NextCell& cell, icrl_stream_t stream) {
+    hipStream_t st = icrl::as_stream(stream);
+    const size_t lds = (size_t)V * sizeof(float);
+    dim3 grid(N), block(256);
+    switch (mode) {
+        case ICRL_SAMPLE:
+            hipLaunchKernelGGL(sample_kernel<ICRL_SAMPLE>, grid, block, lds, st, logits, ld_logits, V, uniforms,
+                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy, cell);
+            break;
+        case ICRL_GREEDY:
+            hipLaunchKernelGGL(sample_kernel<ICRL_GREEDY>, grid, block, 0, st, logits, ld_logits, V, uniforms,
+                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy, cell);
+            break;
+        case ICRL_FORCED:
+            hipLaunchKernelGGL(sample_kernel<ICRL_FORCED>, grid, block, lds, st, logits, ld_logits, V, uniforms,
+                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy, cell);
+            break;
+        default:
+            icrl::set_error("icrl_sample_tokens: unknown mode %d", mode);
+            return ICRL_ERR_ARG;
+    }
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+}  // namespace
+
 extern "C" int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int mode,
                                   const double* uniforms, int64_t* tokens_out, int64_t token_stride,
                                   float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
@@ -237,28 +310,26 @@ extern "C" int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N,
     ICRL_REQUIRE(ld_logits >= V, "icrl_sample_tokens: ld_logits < V");
     ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_sample_tokens: vocabulary %d exceeds the 16384-entry LDS row", V);
     ICRL_REQUIRE(mode != ICRL_SAMPLE || uniforms, "icrl_sample_tokens: ICRL_SAMPLE needs uniforms");
-    hipStream_t st = icrl::as_stream(stream);
-    const size_t lds = (size_t)V * sizeof(float);
-    dim3 grid(N), block(256);
-    switch (mode) {
-        case ICRL_SAMPLE:
-            hipLaunchKernelGGL(sample_kernel<ICRL_SAMPLE>, grid, block, lds, st, logits, ld_logits, V, uniforms,
-                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy);
-            break;
-        case ICRL_GREEDY:
-            hipLaunchKernelGGL(sample_kernel<ICRL_GREEDY>, grid, block, 0, st, logits, ld_logits, V, uniforms,
-                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy);
-            break;
-        case ICRL_FORCED:
-            hipLaunchKernelGGL(sample_kernel<ICRL_FORCED>, grid, block, lds, st, logits, ld_logits, V, uniforms,
-                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy);
-            break;
-        default:
-            icrl::set_error("icrl_sample_tokens: unknown mode %d", mode);
-            return ICRL_ERR_ARG;
-    }
-    ICRL_LAUNCH_CHECK();
-    return ICRL_OK;
+    return launch_sampler(logits, ld_logits, N, V, mode, uniforms, tokens_out, token_stride, log_prob, log_prob_stride,
+                          probs, entropy, NextCell{}, stream);
+}
+
+extern "C" int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logits, int N, int V, int mode,
+                                            const double* uniforms, int64_t* tokens_out, int64_t token_stride,
+                                            float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
+                                            const float* pre, int64_t ld_pre, const float* table, float* gates_out,
+                                            const float* c_prev, float* c_out, float* h_out, icrl_stream_t stream) {
+    ICRL_REQUIRE(logits && tokens_out && N > 0 && V > 0, "icrl_sample_tokens_lstm_cell: null pointer or empty shape");
+    ICRL_REQUIRE(ld_logits >= V, "icrl_sample_tokens_lstm_cell: ld_logits < V");
+    ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_sample_tokens_lstm_cell: vocabulary %d exceeds the 16384-entry LDS row", V);
+    ICRL_REQUIRE(mode == ICRL_SAMPLE || mode == ICRL_FORCED, "icrl_sample_tokens_lstm_cell: mode must be ICRL_SAMPLE or ICRL_FORCED");
+    ICRL_REQUIRE(mode != ICRL_SAMPLE || uniforms, "icrl_sample_tokens_lstm_cell: ICRL_SAMPLE needs uniforms");
+    ICRL_REQUIRE(pre && table && gates_out && c_prev && c_out && h_out, "icrl_sample_tokens_lstm_cell: null cell operand");
+    ICRL_REQUIRE(ld_pre >= 2048 && ld_pre % 2 == 0 && reinterpret_cast<uintptr_t>(pre) % 8 == 0,
+                 "icrl_sample_tokens_lstm_cell: pre must be 8-byte aligned with an even row stride >= 2048");
+    NextCell cell{pre, ld_pre, table, gates_out, c_prev, c_out, h_out};
+    return launch_sampler(logits, ld_logits, N, V, mode, uniforms, tokens_out, token_stride, log_prob, log_prob_stride,
+                          probs, entropy, cell, stream);
 }
 
 extern "C" int icrl_topk_rows(const float* logits, int64_t ld_logits, int N, int V, int k, float* values,

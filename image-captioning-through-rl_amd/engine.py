@@ -460,46 +460,94 @@ class A2CEngine:
                 return cand
         return first
 
-    def _rollout(self, ws, features, n, p0, s, uniforms, mode):
+    NEXT_CELL_FROM = 2   # first rollout step whose cell update is done by the previous step's sampler launch
+
+    def _policy_table_wanted(self, n, p0, s, mode):
+        """Whether the rollout takes the policy LSTM's input side from a per-word table and its cell update from
+        the sampler launch: float32 arithmetic, a sampled or forced rollout, and enough (step, row) pairs that a
+        table over the whole vocabulary is no more work than the products it replaces."""
+        t_steps = p0 - 1 + s
+        return (self.pd == "f32" and mode != hip.GREEDY and self.vocab % 4 == 0 and s >= 4
+                and 2 * t_steps * n >= self.vocab)
+
+    def _policy_table(self, ws):
+        """Per-word input side of the policy LSTM, table[w] = W_ih emb[w] + b_ih + b_hh (models.py:73, 80), and
+        the vocabulary projection stacked on W_hh, so that one product gives a step's logits and the recurrent
+        half of the next step's gates.  They depend on the parameters only: built beside the first rollout steps."""
+        P, V = self.P, self.vocab
+        if "table_p" not in ws:
+            dev = self.device
+            ws["table_p"] = torch.empty(V, 4 * H, dtype=torch.float32, device=dev)
+            ws["Wcat"] = torch.empty(V + 4 * H, H, dtype=torch.float32, device=dev)
+            ws["bcat"] = torch.zeros(V + 4 * H, dtype=torch.float32, device=dev)
+            ws["logits_ext"] = torch.empty(ws["logits"].shape[0], V + 4 * H, dtype=torch.float32, device=dev)
+        ws["Wcat"][:V].copy_(P["linear2vocab.weight"])
+        ws["Wcat"][V:].copy_(P["lstm.weight_hh_l0"])
+        ws["bcat"][:V].copy_(P["linear2vocab.bias"])
+        hip.gemm(P["caption_embedding.weight"], P["lstm.weight_ih_l0"], ws["table_p"], bias=P["lstm.bias_ih_l0"],
+                 bias2=P["lstm.bias_hh_l0"])
+
+    def _rollout(self, ws, features, n, p0, s, uniforms, mode, ev_table=None):
         """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
         from column to column, only the newest position projected to the vocabulary and sampled (or
-        arg-maxed, or scored against the forced token).  (Cutting the rows into two groups issued
-        alternately on two streams was measured and gains nothing: 2.30-2.37 ms against 2.26-2.33.)"""
+        arg-maxed, or scored against the forced token).  With ev_table (the event after which _policy_table's
+        outputs are complete) a step is two launches: [logits | h.W_hh] as one product, then the sampler, whose
+        workgroups go on to the next cell update of their row with the table row of the token they fixed.
+        (Measured and dropped: the rows cut into two groups issued alternately on two streams, 2.30-2.37 ms
+        against 2.26-2.33; the rollout on a high-priority stream while the tables are built beside it, 2.65 ms
+        against 2.30.)"""
         P = self.P
         t_steps = p0 - 1 + s
-        Hb = ws["Hbuf"]
+        Hb, Cb, gates = ws["Hbuf"], ws["Cbuf"], ws["gates"]
+        tokT, V = ws["tokT"], self.vocab
         # h0 = cnn2linear(features): a 64-tile output with a long k, first on the step's critical path; k is
         # split over workgroups (partial slabs summed on top of the bias)
         Hb[0].copy_(P["cnn2linear.bias"].expand_as(Hb[0]))
         hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True, dtype=self.pd)
         fused_step = self.E % 64 == 0 and self.pd == "f32"
+        cell_done = False
         for k in range(t_steps):
-            self._rollout_step(ws, k, 0, n, n, p0, uniforms, mode, fused_step)
+            if not cell_done:
+                self._rollout_cell(ws, k, n, fused_step)
+            cell_done = False
+            if k < p0 - 1:
+                continue
+            st = k - (p0 - 1)
+            out = dict(uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n], log_prob=ws["logp"][st],
+                       probs=ws["probs"][st] if mode != hip.GREEDY else None,
+                       entropy=ws["entropy"][st] if (self.want_entropy and mode != hip.GREEDY) else None)
+            if ev_table is not None and self.NEXT_CELL_FROM <= k + 1 < t_steps:
+                if ev_table is not True:
+                    torch.cuda.current_stream().wait_event(ev_table)
+                    ev_table = True
+                ext = ws["logits_ext"][:n]
+                hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3)
+                hip.sample_tokens_lstm_cell(ext[:, :V], mode, tokT[k + 1], 1, ext[:, V:], ws["table_p"], gates[k + 1],
+                                            Cb[k + 1], Cb[k + 2], Hb[k + 2], **out)
+                cell_done = True
+            else:
+                logits = ws["logits"][:n]
+                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], logits, bias=P["linear2vocab.bias"], dtype=self.pd)
+                hip.sample_tokens(logits, mode, tokT[k + 1], 1, **out)
+        # the embedding rows of the steps that took their input side from the table are gathered when the
+        # backward pass asks for them
+        ws["X_pending"] = ev_table is not None
 
-    def _rollout_step(self, ws, k, lo, hi, n, p0, uniforms, mode, fused_step):
-        """Step k of the rollout for rows [lo, hi) on the current stream."""
+    def _rollout_cell(self, ws, k, n, fused_step):
+        """The policy LSTM's step k for all rows (models.py:73, 80): embedding lookup, both gate products, cell."""
         P = self.P
         tokT = ws["tokT"]
         Hb, Cb, gates, X = ws["Hbuf"], ws["Cbuf"], ws["gates"], ws["X"]
-        r = slice(lo, hi)
         if fused_step:  # gather + both gate products + cell in one launch
-            hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k][r], P["lstm.weight_ih_l0"],
-                                 P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k][r], Cb[k][r],
-                                 gates[k][r], Cb[k + 1][r], Hb[k + 1][r], X[k][r])
+            hip.policy_lstm_step(P["caption_embedding.weight"], tokT[k], P["lstm.weight_ih_l0"],
+                                 P["lstm.weight_hh_l0"], P["lstm.bias_ih_l0"], P["lstm.bias_hh_l0"], Hb[k], Cb[k],
+                                 gates[k], Cb[k + 1], Hb[k + 1], X[k])
         else:
-            hip.gather_rows(P["caption_embedding.weight"], tokT[k][r], 1, hi - lo, X[k][r])
-            hip.gemm(X[k][r], P["lstm.weight_ih_l0"], gates[k][r], bias=P["lstm.bias_ih_l0"],
+            hip.gather_rows(P["caption_embedding.weight"], tokT[k], 1, n, X[k])
+            hip.gemm(X[k], P["lstm.weight_ih_l0"], gates[k], bias=P["lstm.bias_ih_l0"],
                      bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
-            hip.gemm(Hb[k][r], P["lstm.weight_hh_l0"], gates[k][r], accumulate=True, dtype=self.pd)
-            hip.lstm_cell_fwd(gates[k][r], Cb[k][r], Cb[k + 1][r], Hb[k + 1][r])
-        if k >= p0 - 1:
-            st = k - (p0 - 1)
-            logits = ws["logits"][r]
-            hip.gemm(Hb[k + 1][r], P["linear2vocab.weight"], logits, bias=P["linear2vocab.bias"], dtype=self.pd)
-            hip.sample_tokens(logits, mode, tokT[k + 1][r], 1,
-                              uniforms=None if uniforms is None else uniforms[st * n + lo:st * n + hi],
-                              log_prob=ws["logp"][st][r], probs=ws["probs"][st][r] if mode != hip.GREEDY else None,
-                              entropy=ws["entropy"][st][r] if (self.want_entropy and mode != hip.GREEDY) else None)
+            hip.gemm(Hb[k], P["lstm.weight_hh_l0"], gates[k], accumulate=True, dtype=self.pd)
+            hip.lstm_cell_fwd(gates[k], Cb[k], Cb[k + 1], Hb[k + 1])
 
     # ------------------------------------------------------------------ pre-training steps
     def policy_ce_step(self, features, captions, valid_steps, row_weight):
@@ -722,12 +770,17 @@ class A2CEngine:
             ev_feat = torch.cuda.Event()
             ev_feat.record(side)
         tables_on = self._check_stream() if self.concurrent else main
+        ev_table_p = None
         with torch.cuda.stream(tables_on):
             tables_on.wait_event(ev_start)
+            if self._policy_table_wanted(n, p0, s, mode):
+                self._policy_table(ws)
+                ev_table_p = torch.cuda.Event()
+                ev_table_p.record(tables_on)
             self._word_tables(ws)
             ev_tables = torch.cuda.Event()
             ev_tables.record(tables_on)
-        self._rollout(ws, features, n, p0, s, uniforms, mode)
+        self._rollout(ws, features, n, p0, s, uniforms, mode, ev_table=ev_table_p)
         self._mark("rollout_done")
         main.wait_event(ev_feat)
         main.wait_event(ev_tables)
@@ -1138,6 +1191,10 @@ class A2CEngine:
         LSTM's backward-through-time."""
         P, gP = self.P, self.gP
         t_steps = p0 - 1 + s
+        if ws.get("X_pending"):
+            hip.gather_rows(P["caption_embedding.weight"], ws["tokT"].view(-1), 1, t_steps * n,
+                            ws["X"].view(t_steps * n, -1))
+            ws["X_pending"] = False
         coef = ws["dlogp"]
         G0 = ws["dlogits"].view(s * n, self.vocab)
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection

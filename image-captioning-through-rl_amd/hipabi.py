@@ -60,6 +60,8 @@ SIGNATURES = {
                                       c_vp]),
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                                    c_vp]),
+    "icrl_sample_tokens_lstm_cell": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                             c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_policy_dlogits": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "icrl_chain_sync_bytes": (c_i64, []),
     "icrl_lstm_chain_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -321,6 +323,24 @@ def sample_tokens(logits, mode, tokens_out, token_stride, *, uniforms=None, log_
     _check(load().icrl_sample_tokens(_ptr(logits), logits.stride(0), n, v, mode, _ptr(uniforms), _ptr(tokens_out),
                                      token_stride, _ptr(log_prob), log_prob_stride, _ptr(probs), _ptr(entropy),
                                      _stream()), "icrl_sample_tokens")
+
+
+def sample_tokens_lstm_cell(logits, mode, tokens_out, token_stride, pre, table, gates_out, c_prev, c_out, h_out, *,
+                            uniforms=None, log_prob=None, log_prob_stride=1, probs=None, entropy=None):
+    """sample_tokens, then the policy LSTM's next cell update in the same launch: gates = pre[i] + table[token_i].
+    logits [N,V] and pre [N,2048] may be column ranges of one wider matrix (row strides are passed)."""
+    n, v = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and tokens_out.dtype == torch.int64
+    assert pre.dtype == torch.float32 and pre.shape == (n, 2048) and pre.stride(1) == 1
+    assert table.shape == (v, 2048) and table.is_contiguous() and table.dtype == torch.float32
+    for t, width in ((gates_out, 2048), (c_prev, 512), (c_out, 512), (h_out, 512)):
+        assert t.dtype == torch.float32 and t.shape == (n, width) and t.is_contiguous()
+    if uniforms is not None:
+        assert uniforms.dtype == torch.float64 and uniforms.is_contiguous() and uniforms.numel() >= n
+    _check(load().icrl_sample_tokens_lstm_cell(_ptr(logits), logits.stride(0), n, v, mode, _ptr(uniforms), _ptr(tokens_out),
+                                               token_stride, _ptr(log_prob), log_prob_stride, _ptr(probs), _ptr(entropy),
+                                               _ptr(pre), pre.stride(0), _ptr(table), _ptr(gates_out), _ptr(c_prev),
+                                               _ptr(c_out), _ptr(h_out), _stream()), "icrl_sample_tokens_lstm_cell")
 
 
 def masked_nll(log_probs, valid_steps, row_weight, loss, d_logp=None):

@@ -158,6 +158,18 @@ int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int
                        float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
                        icrl_stream_t stream);
 
+/* icrl_sample_tokens (modes ICRL_SAMPLE and ICRL_FORCED) followed, in the same launch, by the policy LSTM's
+ * NEXT cell update for every row (models.py:73, 80 for the token just fixed): the workgroup that fixed row i's
+ * token w forms gates = pre[i] + table[w], applies the cell to c_prev[i] and writes the activated gates
+ * (i, f, g, o; [N,2048]), c_out and h_out ([N,512]).  pre [N, >= 2048] (row stride ld_pre) = h . W_hh^T of the
+ * state the logits were computed from, without bias; table [V,2048] = W_ih emb[w] + b_ih + b_hh for every
+ * word w.  One launch less, and no matrix product, between a token and the next step's logits. */
+int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logits, int N, int V, int mode,
+                                 const double* uniforms, int64_t* tokens_out, int64_t token_stride,
+                                 float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
+                                 const float* pre, int64_t ld_pre, const float* table, float* gates_out,
+                                 const float* c_prev, float* c_out, float* h_out, icrl_stream_t stream);
+
 /* values[r, 0..k) / indices[r, 0..k) = the k largest entries of logits[r, 0..V) in descending order,
  * ties by lowest index: torch.topk(output[:, -1:, :], beamSize) of the look-ahead decoder,
  * trainers.py:96.  k <= 64, V <= 16384. */

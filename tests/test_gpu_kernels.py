@@ -629,3 +629,36 @@ def test_bf16_gemm_with_row_gather_and_strided_output():
     want = torch.from_numpy(table[idx]).bfloat16().double() @ torch.from_numpy(w).bfloat16().double().t()
     np.testing.assert_allclose(out[:, 8:48].cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-5)
     assert float(out[:, :8].abs().max()) == 0.0 and float(out[:, 48:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["sample", "forced"])
+def test_sampler_with_next_cell_update(mode):
+    """icrl_sample_tokens_lstm_cell against icrl_sample_tokens followed by the cell on gates = pre + table[token]:
+    tokens, log-probs and probabilities bit-equal (the sampling part is the same code), gates / c / h against a
+    float64 cell; logits and pre are column ranges of one wide matrix, as the rollout passes them."""
+    rs = np.random.RandomState(11)
+    n, v, hh = 37, 1000, 512
+    ext = dev(rnd(rs, n, v + 4 * hh))
+    table = dev(rnd(rs, v, 4 * hh))
+    c_prev = dev(rnd(rs, n, hh))
+    u = torch.from_numpy(rs.random_sample(n)).cuda()
+    m = hip.SAMPLE if mode == "sample" else hip.FORCED
+    forced = torch.from_numpy(rs.randint(0, v, size=n)).cuda()
+    tok_a, tok_b = forced.clone(), forced.clone()
+    lp_a, lp_b = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pr_a, pr_b = torch.zeros(n, v, device="cuda"), torch.zeros(n, v, device="cuda")
+    logits = ext[:, :v].contiguous()
+    hip.sample_tokens(logits, m, tok_a, 1, uniforms=u if mode == "sample" else None, log_prob=lp_a, probs=pr_a)
+    gates, c_out, h_out = (torch.zeros(n, w, device="cuda") for w in (4 * hh, hh, hh))
+    hip.sample_tokens_lstm_cell(ext[:, :v], m, tok_b, 1, ext[:, v:], table, gates, c_prev, c_out, h_out,
+                                uniforms=u if mode == "sample" else None, log_prob=lp_b, probs=pr_b)
+    torch.cuda.synchronize()
+    assert torch.equal(tok_a, tok_b) and torch.equal(lp_a, lp_b) and torch.equal(pr_a, pr_b)
+    pre = ext[:, v:].double().cpu() + table.double().cpu()[tok_b.cpu()]
+    i, f, g, o = (pre[:, q * hh:(q + 1) * hh] for q in range(4))
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c = f * c_prev.double().cpu() + i * g
+    h = o * torch.tanh(c)
+    np.testing.assert_allclose(gates.cpu().numpy(), torch.cat((i, f, g, o), 1).numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(c_out.cpu().numpy(), c.numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(h_out.cpu().numpy(), h.numpy(), rtol=2e-6, atol=2e-6)

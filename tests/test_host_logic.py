@@ -171,7 +171,8 @@ def test_full_calls_follow_the_warmups_and_the_failed_replay_checks():
     eng = object.__new__(engine.A2CEngine)
     eng.collapse, eng._replay_need = True, 0
     assert eng._full_calls(512, 1, 19, 96, 96) == 1            # replays of >= 512 positions, 128 checked
-    assert eng._full_calls(512, 1, 19, 448, 96) == 2           # 560 steps to check: one more call in full
+    assert eng._full_calls(512, 1, 19, 448, 96) == 1           # 448 steps to check still fit a 512-position replay
+    assert eng._full_calls(512, 1, 19, 640, 96) == 2           # 640 do not: one more call in full
     assert eng._full_calls(512, 1, 19, 96, 600) == 2           # a gradient that reaches 600 positions back
     assert eng._full_calls(64, 1, 19, 96, 96) == 2             # short columns: two of them per replay
     assert eng._full_calls(512, 4, 16, 96, 96) == 1            # a curriculum level's longer prefix
