@@ -51,10 +51,28 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _through_host(t):
+    """Whether a collective on tensor t is staged through host memory by this module: device tensors under a
+    backend other than RCCL (gloo: rehearsals of the N > 1 path with several ranks on one GPU).  The staging is
+    explicit - a synchronous copy to the host, the collective on the host tensor, a copy back - rather than
+    left to the backend's own handling of device tensors."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def _sum_over_ranks(t):
+    """In-place sum over ranks of t (any device)."""
+    if _through_host(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def average_gradients(flat_grad):
     """In-place mean over ranks of the flat gradient buffer (sum, then divide)."""
     if _active():
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        _sum_over_ranks(flat_grad)
         flat_grad.div_(world_size())
     return flat_grad
 
@@ -76,7 +94,11 @@ class GradientAverager:
         if not _active() or self._work is not None:
             return
         piece = self.flat_grad[self.lo:self.hi]
-        if piece.is_cuda:
+        if _through_host(piece):
+            # host-staged: nothing can start before the range is complete; finish() waits for that and reduces
+            # this piece first, so every rank still issues the same collectives in the same order
+            self._work = ("host", ready_event)
+        elif piece.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=piece.device)
             if ready_event is not None:
@@ -94,12 +116,18 @@ class GradientAverager:
         if not _active():
             return self.flat_grad
         if self._work is None:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            _sum_over_ranks(self.flat_grad)
         else:
+            staged = isinstance(self._work, tuple)
+            if staged:
+                if self._work[1] is not None:
+                    self._work[1].synchronize()
+                _sum_over_ranks(self.flat_grad[self.lo:self.hi])
             for lo, hi in ((0, self.lo), (self.hi, self.flat_grad.numel())):
                 if hi > lo:
-                    dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM)
-            self._work.wait()   # CUDA: the current stream waits for the collective's stream
+                    _sum_over_ranks(self.flat_grad[lo:hi])
+            if not staged:
+                self._work.wait()   # CUDA: the current stream waits for the collective's stream
             self._work = None
         self.flat_grad.div_(world_size())
         return self.flat_grad
@@ -108,15 +136,21 @@ class GradientAverager:
 def broadcast_parameters(flat, src=0):
     """Make every rank start from rank `src`'s parameters."""
     if _active():
-        dist.broadcast(flat, src=src)
+        if _through_host(flat):
+            h = flat.detach().cpu()
+            dist.broadcast(h, src=src)
+            flat.copy_(h)
+        else:
+            dist.broadcast(flat, src=src)
     return flat
 
 
 def max_over_ranks(value, device):
     """Max of a python float over ranks (bench timing)."""
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if _active():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if not _active():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 

@@ -464,11 +464,10 @@ class A2CEngine:
 
     def _policy_table_wanted(self, n, p0, s, mode):
         """Whether the rollout takes the policy LSTM's input side from a per-word table and its cell update from
-        the sampler launch: float32 arithmetic, a sampled or forced rollout, and enough (step, row) pairs that a
-        table over the whole vocabulary is no more work than the products it replaces."""
+        the sampler launch: a sampled or forced rollout, and enough (step, row) pairs that a table over the whole
+        vocabulary is no more work than the products it replaces."""
         t_steps = p0 - 1 + s
-        return (self.pd == "f32" and mode != hip.GREEDY and self.vocab % 4 == 0 and s >= 4
-                and 2 * t_steps * n >= self.vocab)
+        return mode != hip.GREEDY and self.vocab % 4 == 0 and s >= 4 and 2 * t_steps * n >= self.vocab
 
     def _policy_table(self, ws):
         """Per-word input side of the policy LSTM, table[w] = W_ih emb[w] + b_ih + b_hh (models.py:73, 80), and
@@ -485,7 +484,7 @@ class A2CEngine:
         ws["Wcat"][V:].copy_(P["lstm.weight_hh_l0"])
         ws["bcat"][:V].copy_(P["linear2vocab.bias"])
         hip.gemm(P["caption_embedding.weight"], P["lstm.weight_ih_l0"], ws["table_p"], bias=P["lstm.bias_ih_l0"],
-                 bias2=P["lstm.bias_hh_l0"])
+                 bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
 
     def _rollout(self, ws, features, n, p0, s, uniforms, mode, ev_table=None):
         """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
@@ -521,7 +520,7 @@ class A2CEngine:
                     torch.cuda.current_stream().wait_event(ev_table)
                     ev_table = True
                 ext = ws["logits_ext"][:n]
-                hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3)
+                hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3, dtype=self.pd)
                 hip.sample_tokens_lstm_cell(ext[:, :V], mode, tokT[k + 1], 1, ext[:, V:], ws["table_p"], gates[k + 1],
                                             Cb[k + 1], Cb[k + 2], Hb[k + 2], **out)
                 cell_done = True

@@ -2,10 +2,7 @@
 their gradients through gloo: the barrier, the max-over-ranks timing, the rank-0 print and the per-rank shards
 of the N > 1 path, run for real.  Needs an MI355X.
 
-The batch stays small on purpose: two ranks that share one GPU AND run in lock step launch their 256-workgroup
-persistent chain kernels at the same instant, each holding part of the CUs while it waits for the rest, and a
-batch-512 step then takes seconds (two processes that are NOT in lock step share the card at 2 x 9 ms a step).
-One process per GPU, the only supported layout, has no such neighbour."""
+The gradients cross through host memory (dist._through_host), staged explicitly."""
 import json
 import os
 import subprocess
@@ -49,3 +46,14 @@ def test_two_rank_bench_prints_one_line_and_keeps_the_ranks_in_step():
     assert out["soak"]["minibatches"] == 6 and out["soak"]["images_per_s"] > 0
     assert "cpu_baseline" not in out   # rank 0 at N = 1 only
     assert out["last_loss"] == out["last_loss"]   # not NaN
+
+
+def test_two_rank_bench_with_persistent_chains_at_batch_512():
+    """Both ranks run the 256-workgroup persistent chain kernels of the batch-512 step on the same GPU, in lock
+    step: no launch may give up waiting for its workgroups.  (Vocabulary and feature width are cut down: they
+    set the size of the gradients, which this rehearsal moves through host memory.)"""
+    out = _launch(2, ["--steps", "2", "--warmup", "1", "--soak", "0", "--vocab", "1000", "--fdim", "512"])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 1024
+    assert out["parameters_identical_across_ranks"] is True
+    assert out["profiled_step"]["plans"]["forward"][:2] == ["segmented", 256]
+    assert out["launches_that_gave_up_waiting"] == 0

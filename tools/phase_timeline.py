@@ -1,4 +1,7 @@
-"""Per-phase GPU timeline of one A2C minibatch at the bench workload (HIP events on the launching streams)."""
+"""Per-phase GPU timeline of one A2C minibatch at the bench workload (HIP events on the launching streams).
+
+    python tools/phase_timeline.py [f32|bf16]
+"""
 import sys, importlib, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import bench
@@ -9,7 +12,7 @@ dev = torch.device("cuda", 0)
 n, vocab, caplen, fdim = 512, 10000, 20, 2048
 a2c, rew, flat, params = bench.build_networks(syn, models, optim, vocab, fdim, 0, dev)
 opt = optim.FusedAdam(flat, lr=1e-4)
-engine = trainers.build_engine(a2c, rew)
+engine = trainers.build_engine(a2c, rew, policy_dtype=sys.argv[1] if len(sys.argv) > 1 else "f32")
 feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, 0)
 fd = torch.from_numpy(feats).to(dev); pd = torch.from_numpy(caps[:, :1]).to(dev)
 u = torch.from_numpy(np.random.RandomState(1).random_sample((6, 19 * n))).to(dev)
