@@ -8,7 +8,7 @@
 // bf16 arithmetic; the recurrent chains never use it.
 //
 // LDS image, both operands: [row][k] bf16 with k contiguous, rows padded to 72 elements (36 dwords: the
-// ds_read_b128 of 16 rows at one k offset is conflict-free).  A k-contiguous source ("MK": [rows][ld]) is
+// ds_read_b128 of 16 rows at one k offset is conflict-free), 16-byte chunks permuted per group of 16 rows (swz).  A k-contiguous source ("MK": [rows][ld]) is
 // staged float4 -> 4 bf16 -> one 8-byte store; a row-contiguous source ("KM": [K][ld]) is transposed on the
 // way: a thread loads the float4 of rows r..r+3 at k and at k+1 and stores four 4-byte {k, k+1} pairs.
 // Fragment of lane (r = lane & 31, h = lane >> 5) for k-step s of 16: elements k = 16s + 8h + j, j = 0..7 of
@@ -35,6 +35,11 @@ struct GemmArgs {
     int64_t slab;      // C offset (floats) between split-K partial results
 };
 
+// The 16-byte chunks (8 bf16) of an LDS row are permuted by the row's group of 16: chunk c of row r sits at
+// c ^ ((r >> 4) & 3).  Reads of 16 consecutive rows at one chunk stay conflict-free, and the transposing stores
+// of a row-contiguous source spread over all banks.
+__device__ __forceinline__ int swz(int row) { return (row >> 4) & 3; }
+
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 p;
@@ -50,8 +55,27 @@ struct Stage {
     static constexpr int PIECES = KM ? ROWS * BK / 8 / 256 : ROWS * BK / 4 / 256;
     float4 r[KM ? 2 * PIECES : PIECES];
 
+    // EDGE = false: the tile lies inside the matrix, rows are not gathered and every float4 is aligned: plain
+    // loads, no branches (so that the compiler can keep several stages' loads outstanding).
+    template <bool EDGE>
     __device__ __forceinline__ void load(const float* base, int64_t ld, const int64_t* gather, int row0, int nrows,
                                          int k0, int kend, int tid) {
+        if (!EDGE) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int f = tid + 256 * i;
+                if (!KM) {
+                    const int row = f >> 4, kq = f & 15;
+                    r[i] = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + row) * ld + k0 + 4 * kq);
+                } else {
+                    const int kp = f / (ROWS / 4), m4 = f % (ROWS / 4);
+                    const float* p = base + (int64_t)(k0 + 2 * kp) * ld + row0 + 4 * m4;
+                    r[2 * i] = *reinterpret_cast<const float4*>(p);
+                    r[2 * i + 1] = *reinterpret_cast<const float4*>(p + ld);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + 256 * i;
@@ -105,11 +129,13 @@ struct Stage {
                 uint2 w;
                 w.x = pack2(r[i].x, r[i].y);
                 w.y = pack2(r[i].z, r[i].w);
-                *reinterpret_cast<uint2*>(lds + row * LDK + 4 * kq) = w;
+                *reinterpret_cast<uint2*>(lds + row * LDK + 8 * ((kq >> 1) ^ swz(row)) + 4 * (kq & 1)) = w;
             } else {
                 const int kp = f / (ROWS / 4), m4 = f % (ROWS / 4);
                 const float4 a = r[2 * i], b = r[2 * i + 1];
-                unsigned* dst = reinterpret_cast<unsigned*>(lds + (4 * m4) * LDK + 2 * kp);
+                // rows 4 m4 .. 4 m4 + 3 share one swizzle; with it the 64 lanes' 4-byte stores (16 row quads x
+                // 4 k pairs) fall into 64 different banks (unswizzled: 4 lanes per bank)
+                unsigned* dst = reinterpret_cast<unsigned*>(lds + (4 * m4) * LDK + 8 * ((kp >> 2) ^ swz(4 * m4)) + 2 * (kp & 3));
                 dst[0] = pack2(a.x, b.x);
                 dst[LDK / 2] = pack2(a.y, b.y);
                 dst[LDK] = pack2(a.z, b.z);
@@ -120,7 +146,64 @@ struct Stage {
 };
 
 __device__ __forceinline__ bf16x8 frag(const __bf16* lds, int row, int kstep, int h) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + row * LDK + 16 * kstep + 8 * h));
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + row * LDK + 8 * ((2 * kstep + h) ^ swz(row))));
+}
+
+// The k loop of one workgroup: acc += A[m0.., kbeg..kend) * B[kbeg..kend), n0..).
+template <int BM, int BN, bool A_KM, bool B_KM, bool EDGE>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[BM / 64][BN / 64], __bf16* lds, int m0, int n0,
+                                       int kbeg, int kend, int nk, int tid) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_TILE = BM * LDK, B_TILE = BN * LDK;
+    constexpr int DEPTH = (BM * BN <= 64 * 64) ? 4 : 2;   // stages in flight in registers (32 / 64 VGPRs each)
+    // Operand tiles travel global -> registers -> LDS.  A workgroup's matrix instructions of one stage take a
+    // fraction of a global load's latency, so DEPTH stages are kept in flight in registers: stage kt + DEPTH is
+    // requested as soon as stage kt has left its registers for LDS.  Loads return in order, so waiting for the
+    // oldest stage leaves the younger ones outstanding.  LDS holds two stages: the one being multiplied and
+    // the one being written; one barrier per stage separates them.
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    Stage<BM, A_KM> sa[DEPTH];
+    Stage<BN, B_KM> sb[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) {
+            sa[d].template load<EDGE>(g.A, g.lda, g.a_rows, m0, g.M, kbeg + d * BK, kend, tid);
+            sb[d].template load<EDGE>(g.B, g.ldb, nullptr, n0, g.N, kbeg + d * BK, kend, tid);
+        }
+
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kt = kt0 + d;
+            if (kt < nk) {
+                __bf16* la = lds + (kt & 1) * (A_TILE + B_TILE);
+                __bf16* lb = la + A_TILE;
+                sa[d].store(la, tid);
+                sb[d].store(lb, tid);
+                if (kt + DEPTH < nk) {
+                    sa[d].template load<EDGE>(g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + DEPTH) * BK, kend, tid);
+                    sb[d].template load<EDGE>(g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + DEPTH) * BK, kend, tid);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    bf16x8 av[TM], bv[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[i] = frag(la, wr * (BM / 2) + i * 32 + l31, ks, h);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bv[j] = frag(lb, wc * (BN / 2) + j * 32 + l31, ks, h);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
 }
 
 template <int BM, int BN, bool A_KM, bool B_KM>
@@ -174,40 +257,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     const int nk = (kend - kbeg + BK - 1) / BK;
     float* const Cout = g.C + (int64_t)split * g.slab;
 
-    Stage<BM, A_KM> sa;
-    Stage<BN, B_KM> sb;
-    sa.load(g.A, g.lda, g.a_rows, m0, g.M, kbeg, kend, tid);
-    sb.load(g.B, g.ldb, nullptr, n0, g.N, kbeg, kend, tid);
-    sa.store(lds, tid);
-    sb.store(lds + A_TILE, tid);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const __bf16* la = lds + (kt & 1) * (A_TILE + B_TILE);
-        const __bf16* lb = la + A_TILE;
-        if (kt + 1 < nk) {   // the next stage's global loads run under this stage's matrix instructions
-            sa.load(g.A, g.lda, g.a_rows, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
-            sb.load(g.B, g.ldb, nullptr, n0, g.N, kbeg + (kt + 1) * BK, kend, tid);
+    const bool aligned = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(g.B) % 16 == 0) &&
+                         g.lda % 4 == 0 && g.ldb % 4 == 0 && kbeg % 4 == 0;
+    // a tile inside the matrix walks its full stages on the branch-free path; a last, partial stage (k not a
+    // multiple of BK) and the tiles on the matrix' edges take the bounds-checked one
+    const bool interior = aligned && !g.a_rows && m0 + BM <= g.M && n0 + BN <= g.N;
+    const int full = (kend - kbeg) / BK;
+    if (interior && full > 0) {
+        k_loop<BM, BN, A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
+        if (full < nk) {
+            __syncthreads();
+            k_loop<BM, BN, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
         }
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = frag(la, wr * (BM / 2) + i * 32 + l31, ks, h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = frag(lb, wc * (BN / 2) + j * 32 + l31, ks, h);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            __bf16* wa = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
-            sa.store(wa, tid);
-            sb.store(wa + A_TILE, tid);
-        }
-        __syncthreads();
+    } else {
+        k_loop<BM, BN, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)

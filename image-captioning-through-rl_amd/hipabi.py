@@ -524,11 +524,10 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
     n = b.shape[1] if b_kmajor else b.shape[0]
     contiguous = out.is_contiguous() and bias is None
     tile, splits = plan_gemm(m, n, k, contiguous, shared)
-    if dtype == "bf16" and contiguous and k >= 2048:
-        # the bf16 kernel's workgroups are bound by the latency of their operand loads, not by the matrix
-        # units: long k loops are cut finer than the f32 plans do (measured: 128x128 tiles with k in eight for
-        # k ~ 10^4, 64x64 tiles with k in four for k ~ 2000)
-        tile, splits = (1, 8) if k >= 4096 else (3, 4)
+    if dtype == "bf16" and contiguous and k >= 2048 and m * n >= (1 << 20):
+        # the bf16 kernel's plans, from its own sweep: long k over large outputs in 128x128 tiles with k in four,
+        # long k over small outputs in 64x64 tiles with k in two, k ~ 2000 unsplit in 64x64 tiles
+        tile, splits = ((1, 4) if m * n >= (1 << 21) else (3, 2)) if k >= 4096 else (3, 1)
     if splits > 1:  # no more partial slabs than the scratch buffer holds
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:
