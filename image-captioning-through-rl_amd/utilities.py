@@ -16,6 +16,58 @@ def print_red(text):
     print('\033[31m', text, '\033[0m', sep='')
 
 
+def _h5_arrays(path, only=None):
+    """Datasets of an HDF5 file as NumPy arrays ({name: array}; `only`: that one dataset).  h5py is imported
+    here, on first use: nothing else in this package needs it."""
+    try:
+        import h5py
+    except ImportError as exc:   # pragma: no cover - depends on the installation
+        raise ImportError("load_data reads the COCO captioning set from HDF5 files and needs h5py (%s)" % exc) from exc
+    with h5py.File(path, "r") as f:
+        if only is not None:
+            return np.asarray(f[only])
+        return {name: np.asarray(ds) for name, ds in f.items()}
+
+
+def _caption_lengths(captions, end_token=2):
+    """Tokens up to and including the first <END> (id 2) of every caption row, as float64 (utilities.py:98-103)."""
+    is_end = np.asarray(captions) == end_token
+    if captions.shape[0] and not is_end.any(axis=1).all():
+        raise ValueError("caption row %d has no <END> token" % int(np.flatnonzero(~is_end.any(axis=1))[0]))
+    return (is_end.argmax(axis=1) + 1).astype(np.float64)
+
+
+def load_data(base_dir, max_train=None, pca_features=True, print_keys=False):
+    """The COCO captioning set of the reference (utilities.py:45-113) as one dict: every dataset of
+    coco2014_captions.h5, train/val fc7 features (PCA-reduced or full), the vocabulary JSON's entries, the URL
+    lists, and `{train,val}_captions_lens`.  max_train draws that many training captions WITH replacement from
+    NumPy's global stream (one np.random.randint call, as the reference)."""
+    import json
+    import os
+    data = dict(_h5_arrays(os.path.join(base_dir, "coco2014_captions.h5")))
+    suffix = "_pca.h5" if pca_features else ".h5"
+    for split in ("train", "val"):
+        data["%s_features" % split] = _h5_arrays(os.path.join(base_dir, "%s2014_vgg16_fc7%s" % (split, suffix)), "features")
+    with open(os.path.join(base_dir, "coco2014_vocab.json")) as f:
+        data.update(json.load(f))
+    for split in ("train", "val"):
+        with open(os.path.join(base_dir, "%s2014_urls.txt" % split)) as f:
+            data["%s_urls" % split] = np.asarray([line.strip() for line in f])
+    if max_train is not None:
+        pick = np.random.randint(data["train_captions"].shape[0], size=max_train)
+        data["train_captions"] = data["train_captions"][pick]
+        data["train_image_idxs"] = data["train_image_idxs"][pick]
+    for split in ("train", "val"):
+        data["%s_captions_lens" % split] = _caption_lengths(data["%s_captions" % split])
+    if print_keys:
+        for key, value in data.items():
+            if isinstance(value, np.ndarray):
+                print(key, type(value), value.shape, value.dtype)
+            else:
+                print(key, type(value), len(value))
+    return data
+
+
 def decode_captions(captions, idx_to_word):
     """Token ids -> strings, dropping <NULL> and stopping after <END> (utilities.py:116-140)."""
     captions = np.asarray(captions.cpu() if torch.is_tensor(captions) else captions)

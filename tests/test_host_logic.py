@@ -185,3 +185,67 @@ def test_full_calls_follow_the_warmups_and_the_failed_replay_checks():
     assert eng._full_calls(512, 1, 19, 96, 96) == 19
     assert hip.chain_positions(512, 1, 19) == 97280 and hip.chain_positions(512, 1, 19, 1) == 9728
     assert hip.chain_positions(512, 1, 19, 2) == 512 * (1 + 2 + 17)
+
+
+def test_load_data_reads_the_coco_layout(tmp_path, monkeypatch):
+    """load_data (reference utilities.py:45-113) against files of the reference's layout.  h5py is not
+    installed here, so a stand-in module that serves arrays from memory takes its place: the file names,
+    keys, the max_train draw from NumPy's global stream and the caption lengths are what is checked; real
+    HDF5 decoding is h5py's business (parity unpinned for it)."""
+    import json
+    import os
+    import sys
+    import types
+    utilities = importlib.import_module("image-captioning-through-rl_amd.utilities")
+    rs = np.random.RandomState(0)
+    caps = rs.randint(3, 50, size=(9, 7))
+    caps[:, 0] = 1
+    ends = rs.randint(2, 7, size=9)
+    for i, e in enumerate(ends):
+        caps[i, e] = 2
+        caps[i, e + 1:] = 0
+    files = {
+        "coco2014_captions.h5": {"train_captions": caps[:6], "train_image_idxs": np.arange(6) % 4,
+                                 "val_captions": caps[6:], "val_image_idxs": np.arange(3) % 2},
+        "train2014_vgg16_fc7_pca.h5": {"features": rs.randn(4, 8).astype(np.float32)},
+        "val2014_vgg16_fc7_pca.h5": {"features": rs.randn(2, 8).astype(np.float32)},
+        "train2014_vgg16_fc7.h5": {"features": rs.randn(4, 16).astype(np.float32)},
+        "val2014_vgg16_fc7.h5": {"features": rs.randn(2, 16).astype(np.float32)},
+    }
+
+    class FakeFile(dict):
+        def __init__(self, path, mode):
+            assert mode == "r"
+            super().__init__(files[os.path.basename(path)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=FakeFile))
+    (tmp_path / "coco2014_vocab.json").write_text(json.dumps({"idx_to_word": ["<NULL>", "<START>", "<END>"],
+                                                              "word_to_idx": {"<NULL>": 0, "<START>": 1, "<END>": 2}}))
+    (tmp_path / "train2014_urls.txt").write_text("a\nb\nc\nd\n")
+    (tmp_path / "val2014_urls.txt").write_text("e\nf\n")
+    data = utilities.load_data(str(tmp_path))
+    assert data["train_features"].shape == (4, 8) and data["val_features"].shape == (2, 8)
+    assert list(data["train_urls"]) == ["a", "b", "c", "d"] and data["word_to_idx"]["<END>"] == 2
+    np.testing.assert_array_equal(data["train_captions_lens"], ends[:6] + 1.0)
+    np.testing.assert_array_equal(data["val_captions_lens"], ends[6:] + 1.0)
+    assert data["train_captions_lens"].dtype == np.float64
+    full = utilities.load_data(str(tmp_path), pca_features=False)
+    assert full["train_features"].shape == (4, 16)
+    np.random.seed(5)
+    want = np.random.randint(6, size=4)
+    np.random.seed(5)
+    sub = utilities.load_data(str(tmp_path), max_train=4)
+    np.testing.assert_array_equal(sub["train_captions"], caps[:6][want])
+    np.testing.assert_array_equal(sub["train_image_idxs"], (np.arange(6) % 4)[want])
+    np.testing.assert_array_equal(sub["train_captions_lens"], (ends[:6] + 1.0)[want])
+    caps_bad = caps.copy()
+    caps_bad[1][caps_bad[1] == 2] = 5
+    files["coco2014_captions.h5"]["train_captions"] = caps_bad[:6]
+    with pytest.raises(ValueError, match="row 1 has no <END>"):
+        utilities.load_data(str(tmp_path))
