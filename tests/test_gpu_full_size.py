@@ -137,3 +137,23 @@ def test_full_size_step_against_the_reference_shaped_cpu_port(full_size):
         for k, g in fs["grads"].items():
             want = out["grad_norms"][k]
             assert abs(float(g.norm()) - want) <= 2e-3 * want + 1e-9, (k, float(g.norm()), want)
+
+
+def test_bf16_policy_arithmetic_at_full_size(full_size):
+    """The opt-in bf16 policy arithmetic at the metric's size, teacher-forced on the float32 step's tokens:
+    the chains and heads are untouched (values and rewards bit-equal), log-probs within rtol 2e-2 + atol 2e-2,
+    the loss within 2e-2, every gradient within 5e-2 (policy) / 2e-2 (value network) of the float32 gradient's
+    L2 norm."""
+    fs = full_size
+    engine = trainers.build_engine(fs["a2c"], fs["rew"], policy_dtype="bf16")
+    res = engine.step(*fs["args"], mode=hip.FORCED, forced_tokens=fs["tokens"]).check()
+    torch.cuda.synchronize()
+    assert torch.equal(res.values, fs["values"]) and torch.equal(res.rewards, fs["rewards"])
+    got, want = res.log_probs.cpu().numpy(), fs["log_probs"].cpu().numpy()
+    assert not np.array_equal(got, want)
+    np.testing.assert_allclose(got, want, rtol=2e-2, atol=2e-2)
+    assert abs(float(res.scalars[0]) - float(fs["scalars"][0])) <= 2e-2 * abs(float(fs["scalars"][0])) + 1e-3
+    for k, p in fs["a2c"].named_parameters():
+        ref = fs["grads"][k]
+        tol = 5e-2 if k.startswith("policy_network.") else 2e-2
+        assert float((p.grad - ref).norm()) <= tol * float(ref.norm()) + 1e-9, (k, float((p.grad - ref).norm()), float(ref.norm()))
