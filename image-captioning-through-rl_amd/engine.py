@@ -855,11 +855,10 @@ class A2CEngine:
             # ---- the backward seam
             restart = False
             while with_bwd and pb[0] == "segmented":
-                # one read-back for the backward seam and the status words (the step's one host sync)
-                ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
-                ev_ctl = torch.cuda.Event()
-                ev_ctl.record(main)
-                ev_ctl.synchronize()
+                # one read-back for the backward seam and the status words (the step's last host sync): it was
+                # queued right behind the chain's BPTT, so the host is released while the weight gradients that
+                # follow are still running and has the optimiser step and the next rollout queued by their end
+                ws["ev_ctl"].synchronize()
                 seam_b = ws["ctl_host"][0:2].tolist()
                 status_host = ws["ctl_host"][4:8].view(torch.int32).tolist()
                 self.last_seam[4:6] = seam_b
@@ -1133,8 +1132,11 @@ class A2CEngine:
                                ws["sync_v"], ws["status"][2:3])
 
         self._mark("value_chain_bwd_done")
-        ev_chain = torch.cuda.Event()
-        ev_chain.record(main)
+        if plan[0] == "segmented":
+            # every word the host reads back (backward seam error, the chain kernels' status words) is final here
+            ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
+            ws["ev_ctl"] = torch.cuda.Event()
+            ws["ev_ctl"].record(main)
         # ---- side stream: the policy network's BPTT beside the value chain
         ev_side = None
         if ev_loss is not None:
