@@ -122,7 +122,8 @@ def load_profile(name):
 def plans_of(res, engine):
     fwd, bwd = res.chain_plan
     return {"forward": list(fwd), "reward_forward": list(res.reward_plan), "backward": list(bwd),
-            "full_calls": res.full_calls, "replay_check": list(engine.last_replay) if engine.last_replay else None}
+            "full_calls": res.full_calls, "replay_check": list(engine.last_replay) if engine.last_replay else None,
+            "warm16_steps": list(engine.last_cheap)}
 
 
 def main():
@@ -150,6 +151,7 @@ def main():
                     help="per_sample: every image owns its value / reward recurrent state (NOT the headline "
                          "workload: a different computation, reported under its own workload name)")
     ap.add_argument("--no-collapse", action="store_true", help="walk every call of the chains in full")
+    ap.add_argument("--no-warm16", action="store_true", help="every warm-up step on the float32 matrix instruction")
     args = ap.parse_args()
     watchdog = float(os.environ.get("ICRL_BENCH_WATCHDOG", "0"))
     if watchdog > 0:   # a run that is still going after this many seconds prints every thread's stack and exits
@@ -174,6 +176,8 @@ def main():
     a2c, rew, flat, params = build_networks(syn, models, optim, vocab, fdim, 0, dev, args.value_forget_bias)
     opt = optim.FusedAdam(flat, lr=1e-4)
     engine_opts = dict(chain_semantics=args.chain_semantics, collapse_replays=not args.no_collapse)
+    if args.no_warm16:
+        engine_opts["warm16"] = False
     if args.policy_dtype != "f32":
         engine_opts["policy_dtype"] = args.policy_dtype
     engine = trainers.build_engine(a2c, rew, **engine_opts)

@@ -680,6 +680,8 @@ struct ChainArgs {
     const float* xproj; const float* w_hh; const float* b_hh;
     const float* state_in;    // {h, c} (GRU: {h}) the chain starts from, or null
     int state_stride;         // floats between the start states of consecutive segments; 0: one state for the chain
+    const float* warm_state;  // [K][H]: every segment's c (GRU: h) after step m_begin - 1, left by seg_warm_pair
+    int m_begin;              // first step walked here (0, or the steps seg_warm_pair walked; hb then holds their h)
     float* hb;                // [2][K][H] exchanged state
     float* saved; float* h_emit; float* seam_a; float* seam_b;
     unsigned* flags;          // [row tiles][16]
@@ -758,6 +760,8 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
     const int rr = tid >> 3, uq = 4 * (tid & 7);
     const int j = row0 + rr, u = u0 + uq;
     float4 state = zero4();            // LSTM: c, GRU: h
+    const int m0 = a.m_begin;
+    if (m0 > 0 && j < g.K) state = ld4(a.warm_state + (int64_t)j * H + u);
     int ps = 0, pt = 0, pi = 0;        // (call, column, row) of the current position
     float4 bias[G == 3 ? 3 : 1];
     if (G == 3) {
@@ -766,7 +770,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
     }
 
     const int steps = g.W + g.Ls;
-    for (int m = 0; m < steps; ++m) {
+    for (int m = m0; m < steps; ++m) {   // flags count the steps walked here: m - m0
         const int cur = m & 1, nxt = cur ^ 1;
         const int qs = m - g.W;     // step within the segment: negative during the warm-up
         const int64_t pos = seg_pos(g, j, qs);
@@ -801,7 +805,7 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
 #pragma unroll
                 for (int i = 0; i < NW; ++i)
                     ring_w[d][i] = W_LOAD(i, d);
-            if (q == 0) wait_row_group(a.flags + by * 16, (unsigned)m, abort_w, lane);
+            if (q == 0) wait_row_group(a.flags + by * 16, (unsigned)(m - m0), abort_w, lane);
             __syncthreads();
             const int a_base = cur * g.K * H * 4;
 #pragma unroll
@@ -941,12 +945,225 @@ __device__ __forceinline__ void persist_chain(const ChainArgs& a, int bx, int by
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
         __syncthreads();                                    // ... before ONE lane signals for all of them
         if (tid == 0)
-            __hip_atomic_store((gu32*)(a.flags + by * 16 + bx), (unsigned)(m + 1), __ATOMIC_RELAXED,
+            __hip_atomic_store((gu32*)(a.flags + by * 16 + bx), (unsigned)(m + 1 - m0), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 #undef W_LOAD
+
+// ------------------------------------------------------------------ the first steps of a warm-up, at 16-bit precision
+// A warm-up's results are thrown away: all that matters is the state it leaves, and the seam check measures
+// that.  Its first steps therefore run on the bf16 matrix instruction, at 1/16 of the f32 instruction's time,
+// with both operands cut in two bf16 pieces (x = hi + mid exactly to 16 significant bits; the three products
+// hi.hi + hi.mid + mid.hi carry 2^-16 relative error).  The f32 launch that follows continues from the state
+// left here (ChainArgs::warm_state, m_begin) with a few more warm-up steps, which wash the 2^-16 out.
+// Plain bf16 (8 bits) is not enough: a long-memory LSTM keeps its 4e-3 error for hundreds of steps.
+//
+// Workgroup (unit tile bx of 16 units, row group by of 32 segments) of one chain; wave q owns gate q and keeps
+// its 16 x 512 slice of W_hh, both pieces, in registers for the whole launch (128 VGPRs), so a step moves only
+// the row group's h: 32 x 512 floats gathered from the 32 workgroups of the group (sc1 loads after the flags),
+// cut into the two planes in LDS, 96 matrix instructions of 16x16x32 per wave, the gate tiles through LDS, the
+// cell for two units per lane with c (GRU: h) in registers, h handed on as in persist_chain.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+constexpr int WLD = H + 8;     // bf16 per LDS row of an h plane: 1040 bytes, so 16 rows at one k fall in 16 x 4 different banks
+constexpr int WGT = 17;        // floats per row of a gate tile
+constexpr int WARM_LDS = 2 * 32 * WLD * 2 + 4 * 32 * WGT * 4;
+
+struct WarmArgs {
+    const float* xproj; const float* w_hh; const float* b_hh;
+    float* hb;              // [2][K][H] exchanged h; the last step leaves its h in buffer steps & 1
+    float* state_out;       // [K][H]: c (GRU: h) after the last step
+    unsigned* flags;        // [row groups][32]
+    Geom g;
+    int steps;              // steps m = 0 .. steps - 1 of the chain's W + Ls are walked here (steps < W)
+};
+
+__device__ __forceinline__ void split2(float x, __bf16& hi, __bf16& mid) {
+    hi = (__bf16)x;
+    mid = (__bf16)(x - (float)hi);
+}
+
+// wave 0: lanes 0..31 each poll one producer's flag, lane 32 polls the abort word
+__device__ __forceinline__ bool wait_row_group32(unsigned* flags32, unsigned epoch, unsigned* abort_w, int lane) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        unsigned v = epoch, ab = 0;
+        if (lane < 32) v = __hip_atomic_load((gu32*)(flags32 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (lane == 32) ab = __hip_atomic_load((gu32*)abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__any(ab != 0)) return false;
+        if (__all(v >= epoch)) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void warm_chain(const WarmArgs& a, int bx, int by, unsigned* abort_w, char* lds_raw) {
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int row0 = by * 32, u0 = bx * 16;
+    __bf16* plane = reinterpret_cast<__bf16*>(lds_raw);                                      // [2][32][WLD]
+    float* gt = reinterpret_cast<float*>(lds_raw + 2 * 32 * WLD * sizeof(__bf16));           // [G][32][WGT]
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.hb, 0, (int)(2 * (int64_t)g.K * H * sizeof(float)), 0x00020000);
+
+    // B operand of lane (column l15, k group kg) at k step ks: W_hh[gate q, unit u0 + l15][32 ks + 8 kg + 0..7]
+    wbf16x8 bw[2][16];
+    if (q < G) {
+        const float* wrow = a.w_hh + ((int64_t)q * H + u0 + l15) * H + 8 * kg;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float4 w0 = ld4(wrow + 32 * ks), w1 = ld4(wrow + 32 * ks + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 hi, mid;
+                split2(w[e], hi, mid);
+                bw[0][ks][e] = hi;
+                bw[1][ks][e] = mid;
+            }
+        }
+    }
+
+    // this lane's epilogue item: segment row j, units u, u + 1; its cell state lives in registers
+    const int rr = tid >> 3, uq = 2 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    float2 state = make_float2(0.f, 0.f);
+    int ps = 0, pt = 0, pi = 0;
+    float2 bias[3];
+    if (G == 3) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) bias[gq] = *reinterpret_cast<const float2*>(a.b_hh + gq * H + u);
+    }
+
+    for (int m = 0; m < a.steps; ++m) {
+        const int cur = m & 1, nxt = cur ^ 1;
+        const int qs = m - g.W;
+        const int64_t pos = seg_pos(g, j, qs);
+        int st = 0;   // 0 = no row, 1 = before the chain's first position (zero state), 2 = live
+        float2 px[G];
+        if (j < g.K) {
+            st = (pos < 0 || pos >= g.total) ? 1 : 2;
+            if (st == 2) {
+                locate_fast(g, (int)pos, ps, pt, pi);
+                const float* xr = a.xproj + ((int64_t)pt * g.n + pi) * (G * H) + u;
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) px[gq] = *reinterpret_cast<const float2*>(xr + gq * H);
+            }
+        }
+        f32x4 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] = 0.f;
+
+        if (m > 0) {
+            if (q == 0) wait_row_group32(a.flags + by * 32, (unsigned)m, abort_w, lane);
+            __syncthreads();
+            // the row group's h: float4 (tid + 256 i) of 32 rows x 128, cut into the hi and mid planes
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {   // eight loads in flight at a time
+                v4u raw[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = tid + 256 * (8 * half + i), row = f >> 7, c4 = f & 127;
+                    raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (min(row0 + row, g.K - 1) * H + 4 * c4) * 4,
+                                                                   cur * g.K * H * 4, SC1);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = tid + 256 * (8 * half + i), row = f >> 7, c4 = f & 127;
+                    const float4 v = as_f4(raw[i]);
+                    wbf16x4 hi, mid;
+                    __bf16 h_, m_;
+                    split2(v.x, h_, m_); hi[0] = h_; mid[0] = m_;
+                    split2(v.y, h_, m_); hi[1] = h_; mid[1] = m_;
+                    split2(v.z, h_, m_); hi[2] = h_; mid[2] = m_;
+                    split2(v.w, h_, m_); hi[3] = h_; mid[3] = m_;
+                    *reinterpret_cast<wbf16x4*>(plane + row * WLD + 4 * c4) = hi;
+                    *reinterpret_cast<wbf16x4*>(plane + (32 + row) * WLD + 4 * c4) = mid;
+                }
+            }
+            __syncthreads();
+            if (q < G) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const __bf16* ar = plane + (mt * 16 + l15) * WLD + 8 * kg;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const wbf16x8 a_hi = *reinterpret_cast<const wbf16x8*>(ar + 32 * ks);
+                        const wbf16x8 a_mid = *reinterpret_cast<const wbf16x8*>(ar + 32 * WLD + 32 * ks);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bw[0][ks], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bw[1][ks], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, bw[0][ks], acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // accumulator register r of lane (l15, kg) is element [row 4 kg + r][column l15] of its 16 x 16 tile
+        if (q < G) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gt[(q * 32 + mt * 16 + 4 * kg + r) * WGT + l15] = acc[mt][r];
+        }
+        __syncthreads();
+
+        if (st != 0) {
+            float2 h = make_float2(0.f, 0.f);
+            if (st == 1) {
+                state = make_float2(0.f, 0.f);
+            } else {
+                const float* pr = gt + rr * WGT + uq;
+                if (G == 4) {
+                    float2 gi = make_float2(pr[0] + px[0].x, pr[1] + px[0].y);
+                    float2 gf = make_float2(pr[32 * WGT] + px[1].x, pr[32 * WGT + 1] + px[1].y);
+                    float2 gg = make_float2(pr[64 * WGT] + px[2].x, pr[64 * WGT + 1] + px[2].y);
+                    float2 go = make_float2(pr[96 * WGT] + px[G - 1].x, pr[96 * WGT + 1] + px[G - 1].y);
+                    float2 c;
+                    LSTM_CELL1(x, gi, gf, gg, go, state, c, h)
+                    LSTM_CELL1(y, gi, gf, gg, go, state, c, h)
+                    state = c;
+                } else {
+                    const float2 hr_ = make_float2(pr[0] + bias[0].x, pr[1] + bias[0].y);
+                    const float2 hz = make_float2(pr[32 * WGT] + bias[1].x, pr[32 * WGT + 1] + bias[1].y);
+                    const float2 hn = make_float2(pr[64 * WGT] + bias[2].x, pr[64 * WGT + 1] + bias[2].y);
+                    GRU_CELL1(x, px[0], px[1], px[2], hr_, hz, hn, state, h)
+                    GRU_CELL1(y, px[0], px[1], px[2], hr_, hz, hn, state, h)
+                    state = h;
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, h), rs, (j * H + u) * 4, nxt * g.K * H * 4, SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store((gu32*)(a.flags + by * 32 + bx), (unsigned)(m + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (j < g.K) *reinterpret_cast<float2*>(a.state_out + (int64_t)j * H + u) = state;
+}
+
+// Both chains' first warm-up steps in one launch.  Block b runs on XCD b % 8; a row group's 32 workgroups are
+// given block ids of one XCD (speed only: every hand-off store is write-through).
+__global__ __launch_bounds__(256, 2) void seg_warm_pair(WarmArgs v, WarmArgs r, unsigned* abort_w, int per_chain, int ny) {
+    extern __shared__ __attribute__((aligned(16))) char warm_lds[];
+    __builtin_amdgcn_s_setprio(3);
+    const int chain = blockIdx.x / per_chain, w = blockIdx.x % per_chain;
+    const int xcd = w & 7, t = w >> 3;
+    const int by = (t >> 5) * 8 + xcd, bx = t & 31;
+    if (by >= ny) return;
+    if (chain == 0) { if (v.steps > 0) warm_chain<4>(v, bx, by, abort_w, warm_lds); }
+    else if (r.steps > 0) warm_chain<3>(r, bx, by, abort_w, warm_lds);
+}
 
 // only: 0 = both chains (2 * per_chain workgroups), 1 = the LSTM chain alone, 2 = the GRU chain alone
 // (per_chain workgroups)
@@ -1264,21 +1481,42 @@ int bwd_steps(const Geom& g, const float* w_hh, const float* saved, const float*
     return ICRL_OK;
 }
 
-// both forward chains in one persistent launch; returns the abort word through *abort_out
-int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipStream_t st, unsigned** abort_out) {
+// both forward chains in one persistent launch; returns the abort word through *abort_out.  cheap_v / cheap_r:
+// the first steps of each chain's warm-up that run on seg_warm_pair (16-bit split products) before it.
+// phase: 0 = everything, 1 = up to and including the cheap warm-up launch, 2 = the float32 launch alone (after a
+// phase-1 call on the same workspaces).
+int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipStream_t st, unsigned** abort_out,
+                 int cheap_v = 0, int cheap_r = 0, int phase = 0) {
     const int K = v.g.K;
     const int64_t kh = (int64_t)K * H;
     const int ny = (K + 31) / 32;
-    // polled words (flags of both chains, abort word): a block of their own, zeroed on every call
+    // polled words (flags of both chains, abort word, flags of the cheap warm-up): a block of their own, zeroed on every call
     unsigned* words = reinterpret_cast<unsigned*>(work_v + 12 * kh);
-    const size_t word_bytes = ((size_t)(2 * ny * 16 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    const size_t word_bytes = ((size_t)(2 * ny * 16 + 4 + 2 * ny * 32) * sizeof(unsigned) + 255) / 256 * 256;
     ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
-    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
-    ICRL_HIP(hipMemsetAsync(work_v, 0, sizeof(float) * 2 * kh, st));
-    ICRL_HIP(hipMemsetAsync(work_r, 0, sizeof(float) * 2 * kh, st));
+    if (phase != 2) {
+        ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+        ICRL_HIP(hipMemsetAsync(work_v, 0, sizeof(float) * 2 * kh, st));
+        ICRL_HIP(hipMemsetAsync(work_r, 0, sizeof(float) * 2 * kh, st));
+    }
     v.hb = work_v; v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
     r.hb = work_r; r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 16;
     *abort_out = words + 2 * ny * 16;
+    if (cheap_v > 0 || cheap_r > 0) {
+        WarmArgs wv{}, wr{};
+        unsigned* wflags = words + 2 * ny * 16 + 4;
+        wv.xproj = v.xproj; wv.w_hh = v.w_hh; wv.b_hh = nullptr; wv.hb = v.hb; wv.state_out = work_v + 2 * kh;
+        wv.flags = wflags; wv.g = v.g; wv.steps = cheap_v;
+        wr.xproj = r.xproj; wr.w_hh = r.w_hh; wr.b_hh = r.b_hh; wr.hb = r.hb; wr.state_out = work_r + 4 * kh;
+        wr.flags = wflags + ny * 32; wr.g = r.g; wr.steps = cheap_r;
+        const int warm_per_chain = (ny + 7) / 8 * 8 * 32;
+        if (phase != 2)
+            hipLaunchKernelGGL(seg_warm_pair, dim3(2 * warm_per_chain), dim3(256), WARM_LDS, st, wv, wr, *abort_out,
+                               warm_per_chain, ny);
+        v.warm_state = wv.state_out; v.m_begin = cheap_v;
+        r.warm_state = wr.state_out; r.m_begin = cheap_r;
+    }
+    if (phase == 1) return ICRL_OK;
     const int per_chain = (H / 32) * ny;
     hipLaunchKernelGGL(seg_fwd_pair_persist, dim3(2 * per_chain), dim3(256), 0, st, v, r, *abort_out, per_chain, 0);
     return ICRL_OK;
@@ -1462,30 +1700,42 @@ extern "C" int icrl_chain_pair_supported(int segments) {
     return 2 * per_chain <= cus * per_cu_fwd && per_chain <= cus * per_cu_bwd ? 1 : 0;
 }
 
-extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
-                                       const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
-                                       int n_calls, int full_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
-                                       float* saved_v, float* h_emit_r, float* saved_r, float* work_v, float* work_r,
-                                       float* seam_err_v, float* seam_err_r, icrl_stream_t stream) {
+namespace {
+int pair_fwd_impl(const char* who, const float* xproj_v, const float* w_hh_v, const float* xproj_r, const float* w_hh_r,
+                  const float* b_hh_r, int N, int p0_v, int p0_r, int n_calls, int full_calls, int segments, int warmup_v,
+                  int warmup_r, int cheap_v, int cheap_r, int phase, float* h_emit_v, float* saved_v, float* h_emit_r,
+                  float* saved_r, float* work_v, float* work_r, float* seam_err_v, float* seam_err_r, icrl_stream_t stream) {
     ChainArgs v{}, r{};
-    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_v, n_calls, full_calls, segments, warmup_v, v.g)) return rc;
-    if (int rc = make_geom("icrl_chain_pair_fwd_seg", N, p0_r, n_calls, full_calls, segments, warmup_r, r.g)) return rc;
+    if (int rc = make_geom(who, N, p0_v, n_calls, full_calls, segments, warmup_v, v.g)) return rc;
+    if (int rc = make_geom(who, N, p0_r, n_calls, full_calls, segments, warmup_r, r.g)) return rc;
     ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r &&
-                 seam_err_v && seam_err_r, "icrl_chain_pair_fwd_seg: null pointer");
+                 seam_err_v && seam_err_r, "%s: null pointer", who);
     ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(xproj_r) && aligned16(w_hh_r) &&
                  aligned16(b_hh_r) && aligned16(h_emit_v) && aligned16(saved_v) && aligned16(h_emit_r) &&
                  aligned16(saved_r) && aligned16(work_v) && aligned16(work_r),
-                 "icrl_chain_pair_fwd_seg: buffers must be 16-byte aligned");
+                 "%s: buffers must be 16-byte aligned", who);
     ICRL_REQUIRE(icrl_chain_pair_supported(segments),
-                 "icrl_chain_pair_fwd_seg: %d segments need more workgroups than the device has CUs; its workgroups "
-                 "wait for each other and must all be resident", segments);
+                 "%s: %d segments need more workgroups than the device has CUs; its workgroups "
+                 "wait for each other and must all be resident", who, segments);
+    ICRL_REQUIRE(cheap_v >= 0 && cheap_r >= 0 && cheap_v < warmup_v && cheap_r < warmup_r,
+                 "%s: the 16-bit part of a warm-up must be shorter than the warm-up (at least one float32 step follows)", who);
+    ICRL_REQUIRE((cheap_v == 0 && cheap_r == 0) || icrl_chain_warm16_supported(segments),
+                 "%s: the 16-bit warm-up launch does not fit the device at %d segments", who, segments);
+    ICRL_REQUIRE(phase >= 0 && phase <= 2 && (phase == 0 || cheap_v > 0 || cheap_r > 0),
+                 "%s: phase must be 0, or 1 / 2 with a 16-bit part to run", who);
     hipStream_t st = icrl::as_stream(stream);
-    ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
-    ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
+    if (phase != 2) {
+        ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
+        ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
+    }
     v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v; v.state_in = nullptr;
     r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = saved_r; r.h_emit = h_emit_r; r.state_in = nullptr;
     unsigned* abort_w = nullptr;
-    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
+    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w, cheap_v, cheap_r, phase)) return rc;
+    if (phase == 1) {
+        ICRL_LAUNCH_CHECK();
+        return ICRL_OK;
+    }
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(v.g.K * 2 * H)), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
                        2 * H, seam_err_v);
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(r.g.K * H)), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
@@ -1493,6 +1743,46 @@ extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v
     hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err_v, seam_err_r);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
+}
+}  // namespace
+
+extern "C" int icrl_chain_warm16_supported(int segments) {
+    // all 2 x 32 x ceil(segments / 32) workgroups of the 16-bit warm-up launch (rounded up to whole groups of 8 row
+    // groups) must be resident at once
+    static int cus = -1, per_cu = 0;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(seg_warm_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WARM_LDS) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seg_warm_pair, 256, WARM_LDS) != hipSuccess) return 0;
+        cus = n;
+    }
+    if (segments < 1) return 0;
+    const int ny = (segments + 31) / 32;
+    return 2 * ((ny + 7) / 8 * 8 * 32) <= cus * per_cu ? 1 : 0;
+}
+
+extern "C" int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                       const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                                       int n_calls, int full_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
+                                       float* saved_v, float* h_emit_r, float* saved_r, float* work_v, float* work_r,
+                                       float* seam_err_v, float* seam_err_r, icrl_stream_t stream) {
+    return pair_fwd_impl("icrl_chain_pair_fwd_seg", xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, N, p0_v, p0_r, n_calls,
+                         full_calls, segments, warmup_v, warmup_r, 0, 0, 0, h_emit_v, saved_v, h_emit_r, saved_r, work_v,
+                         work_r, seam_err_v, seam_err_r, stream);
+}
+
+extern "C" int icrl_chain_pair_fwd_seg_warm16(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                              const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                                              int n_calls, int full_calls, int segments, int warmup_v, int warmup_r,
+                                              int cheap_v, int cheap_r, int phase, float* h_emit_v, float* saved_v,
+                                              float* h_emit_r, float* saved_r, float* work_v, float* work_r,
+                                              float* seam_err_v, float* seam_err_r, icrl_stream_t stream) {
+    return pair_fwd_impl("icrl_chain_pair_fwd_seg_warm16", xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, N, p0_v, p0_r,
+                         n_calls, full_calls, segments, warmup_v, warmup_r, cheap_v, cheap_r, phase, h_emit_v, saved_v,
+                         h_emit_r, saved_r, work_v, work_r, seam_err_v, seam_err_r, stream);
 }
 
 extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,

@@ -182,7 +182,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
-                 frozen_reward=False,
+                 frozen_reward=False, warm16=True,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -208,6 +208,9 @@ class A2CEngine:
         # without calling parameters_changed(); what depends on them alone is then computed once
         self.frozen_reward, self._param_epoch = bool(frozen_reward), 0
         self.max_segments = int(max_segments)
+        # the first part of the forward warm-ups at 16-bit split precision (see _cheap_steps)
+        self.warm16, self._warm16_off, self._warm16_penalty = bool(warm16), 0, 32
+        self.last_cheap = (0, 0)     # 16-bit warm-up steps (value, reward chain) of the last forward pair launch
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
         self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
         self.last_replay = None      # (full_calls, steps, err value chain, err reward chain) of the last step
@@ -365,6 +368,28 @@ class A2CEngine:
         k = ws["segments"]
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
+
+    WARM16_MIN_WARMUP = 128   # shorter warm-ups gain nothing: the extra launch costs what its steps save
+    WARM16_TAIL = 16   # float32 steps that end a warm-up whose first part ran at 16-bit precision (at least W / 8)
+
+    def _note_cheap(self, plan, plan_r):
+        self.last_cheap = self._cheap_steps(plan[1], plan[2], plan_r[2])
+        return self.last_cheap
+
+    def _warm16_active(self, pv, pr):
+        return pv[0] == "segmented" and pr[0] == "segmented" and any(self._cheap_steps(pv[1], pv[2], pr[2]))
+
+    def _cheap_steps(self, segments, w_v, w_r):
+        """(value, reward): how many of each forward chain's warm-up steps run at 16-bit split precision
+        (icrl_chain_pair_fwd_seg_warm16) before the float32 launch; a float32 tail of max(WARM16_TAIL, W / 8)
+        steps washes their 2^-16 out.  Switched off for a while (32 minibatches, doubling) after a forward seam
+        was rejected with it in use, so that a network it does not suit costs a redone minibatch now and then,
+        not the warm-up ladder."""
+        if (not self.warm16 or self._warm16_off > 0 or max(w_v, w_r) < self.WARM16_MIN_WARMUP
+                or not hip.chain_warm16_supported(segments)):
+            return 0, 0
+        cut = lambda w: max(0, w - max(self.WARM16_TAIL, w // 8))
+        return cut(w_v), cut(w_r)
 
     def _replay_steps(self, w_fwd):
         """Steps of a left-out replay that the check walks: the longest forward warm-up in use (the seams say
@@ -787,8 +812,7 @@ class A2CEngine:
         ws["policy_early"] = False
         if backward and mode != hip.GREEDY:
             self._order_tokens(ws, n, (p0 - 1 + s) * n, main, side)
-            if self.concurrent:
-                self._policy_backward_early(ws, n, p0, s, main, self._check_stream())
+            ws["early_pending"] = bool(self.concurrent)
         last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
         with_bwd = backward and mode != hip.GREEDY
@@ -823,6 +847,11 @@ class A2CEngine:
                         # kernels held the CUs): that says nothing about the warm-up, so the same plans run once more
                         gave_up += 1
                         self.launch_timeouts += 1
+                        continue
+                    if self._warm16_active(pv, pr) and not (self._ladder_fv.probing or self._ladder_fr.probing):
+                        # the 16-bit part of the warm-up may be what failed (not so when a shorter warm-up was being
+                        # tried: then that is what failed): the same plans again without it
+                        self._warm16_off, self._warm16_penalty = self._warm16_penalty, min(2 * self._warm16_penalty, 1024)
                         continue
                     if not ok_v:
                         fv = self._next_rung(fv, checks_v)
@@ -879,6 +908,7 @@ class A2CEngine:
                 continue
             break
         self._replay_accepted()
+        self._warm16_off = max(0, self._warm16_off - 1)
         # the tensors handed back are final now; their copies queue behind the backward pass
         out = (tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                ws["rewards"].view(s, n).t().contiguous())
@@ -899,6 +929,11 @@ class A2CEngine:
             hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["table_r"],
                      bias=R["rewrnn.gru.bias_ih_l0"])
             ws["table_r_epoch"] = self._param_epoch
+
+    def _early_now(self, ws, n, p0, s, main):
+        """Start the loss-independent part of the policy backward pass, if this step wants it and has not yet."""
+        if ws.pop("early_pending", False):
+            self._policy_backward_early(ws, n, p0, s, main, self._check_stream())
 
     def _policy_backward_early(self, ws, n, p0, s, main, stream):
         """The part of the policy network's backward pass that needs no loss: d logits up to the per-row
@@ -982,6 +1017,8 @@ class A2CEngine:
         # (per-row chains: always one call for both, persistent or a launch per step)
         pair = rows or (seg and seg_r and self.persistent and hip.chain_pair_supported(plan[1]))
         assert pair or not collapsed or (seg and seg_r), "replays are only left out on the segmented kernels"
+        if rows or not pair:
+            self._early_now(ws, n, p0, s, main)
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
         with torch.cuda.stream(side):
@@ -1012,11 +1049,21 @@ class A2CEngine:
                                     ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
                                     ws["status"][0:1], persistent=self.persistent and hip.chain_pair_supported(n))
         elif pair:
-            hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
-                                   R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
-                                   ws["saved"] if keep else None, ws["hr"], ws["work_v"], ws["work_r"],
-                                   ws["seam"][0:2], ws["seam"][2:4], warmup_r=plan_r[2], full_calls=fc,
-                                   saved_r=ws["saved_r"] if collapsed else None)
+            cheap = self._note_cheap(plan, plan_r)
+            pair_args = (ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
+                         R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
+                         ws["saved"] if keep else None, ws["hr"], ws["work_v"], ws["work_r"], ws["seam"][0:2],
+                         ws["seam"][2:4])
+            pair_opts = dict(warmup_r=plan_r[2], full_calls=fc, saved_r=ws["saved_r"] if collapsed else None, cheap=cheap)
+            if any(cheap):
+                # the 16-bit launch needs every CU's registers: it goes first, and what runs beside the chains
+                # on the other streams is released behind it
+                hip.chain_pair_fwd_seg(*pair_args, phase=1, **pair_opts)
+                self._early_now(ws, n, p0, s, main)
+                hip.chain_pair_fwd_seg(*pair_args, phase=2, **pair_opts)
+            else:
+                self._early_now(ws, n, p0, s, main)
+                hip.chain_pair_fwd_seg(*pair_args, **pair_opts)
         ev_seam = None
         if pair:
             ev_seam = self._seam_to_host(ws, main)

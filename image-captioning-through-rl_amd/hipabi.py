@@ -39,6 +39,8 @@ SIGNATURES = {
     "icrl_gru_chain_fwd_seg_persist": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 5),
     "icrl_lstm_chain_bwd_seg_persist": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp] * 9),
+    "icrl_chain_pair_fwd_seg_warm16": (c_int, [c_vp] * 5 + [c_int] * 11 + [c_vp] * 9),
+    "icrl_chain_warm16_supported": (c_int, [c_int]),
     "icrl_chain_pair_replay_check": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
     "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -593,27 +595,43 @@ def chain_pair_supported(segments):
     return bool(load().icrl_chain_pair_supported(int(segments)))
 
 
+def chain_warm16_supported(segments):
+    return bool(load().icrl_chain_warm16_supported(int(segments)))
+
+
 def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, segments, warmup, h_emit_v,
                        saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r, warmup_r=None, full_calls=0,
-                       saved_r=None):
+                       saved_r=None, cheap=(0, 0), phase=0):
     """Value LSTM chain and reward GRU chain, every step, in one persistent launch (warmup_r: the
-    reward chain's own warm-up length; default: the value chain's)."""
+    reward chain's own warm-up length; default: the value chain's).  cheap = (value, reward): the first steps of
+    each warm-up that run at 16-bit split precision in a launch of their own (icrl_chain_pair_fwd_seg_warm16);
+    phase 1 queues that launch alone, phase 2 (same arguments) the rest."""
     _chain_shapes("chain_pair_fwd_seg (value)", n, p0_v, n_calls, 4, xproj=xproj_v, w_hh=w_hh_v, h_emit=h_emit_v,
                   saved=saved_v, slots=6, work=work_v, segments=segments, full_calls=full_calls)
     _chain_shapes("chain_pair_fwd_seg (reward)", n, p0_r, n_calls, 3, xproj=xproj_r, w_hh=w_hh_r, h_emit=h_emit_r,
                   saved=saved_r, slots=5, work=work_r, segments=segments, full_calls=full_calls)
     warmup_r = warmup if warmup_r is None else warmup_r
-    with _Timed("chain_pair_fwd", chain_positions(n, p0_v, n_calls, full_calls) + chain_positions(n, p0_r, n_calls, full_calls),
-                steps=max(_seg_steps(n, p0_v, n_calls, full_calls, segments, warmup),
-                          _seg_steps(n, p0_r, n_calls, full_calls, segments, warmup_r)),
-                flops=2.0 * segments * 512 * 512 * (4 * _seg_steps(n, p0_v, n_calls, full_calls, segments, warmup) +
-                                                    3 * _seg_steps(n, p0_r, n_calls, full_calls, segments, warmup_r))):
-        rc = load().icrl_chain_pair_fwd_seg(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)),
-                                            _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)), n, p0_v, p0_r, n_calls, full_calls,
-                                            segments, warmup, warmup_r,
-                                            _ptr(_f32c(h_emit_v)), _ptr(saved_v),
-                                            _ptr(_f32c(h_emit_r)), _ptr(saved_r), _ptr(_f32c(work_v)), _ptr(_f32c(work_r)),
-                                            _ptr(seam_err_v), _ptr(seam_err_r), _stream())
+    steps_v = _seg_steps(n, p0_v, n_calls, full_calls, segments, warmup)
+    steps_r = _seg_steps(n, p0_r, n_calls, full_calls, segments, warmup_r)
+    positions = chain_positions(n, p0_v, n_calls, full_calls) + chain_positions(n, p0_r, n_calls, full_calls)
+    if phase == 1:    # the 16-bit launch alone: no float32 matrix-instruction work
+        timed = _Timed("chain_warm16", 0, steps=max(cheap))
+    else:
+        # float32 matrix-instruction work: the steps that do not run at 16-bit split precision; a phase-2 call
+        # walks only those
+        walked = max(steps_v - cheap[0], steps_r - cheap[1]) if phase == 2 else max(steps_v, steps_r)
+        timed = _Timed("chain_pair_fwd", positions, steps=walked,
+                       flops=2.0 * segments * 512 * 512 * (4 * (steps_v - cheap[0]) + 3 * (steps_r - cheap[1])))
+    with timed:
+        head = (_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(xproj_r)), _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)),
+                n, p0_v, p0_r, n_calls, full_calls, segments, warmup, warmup_r)
+        tail = (_ptr(_f32c(h_emit_v)), _ptr(saved_v), _ptr(_f32c(h_emit_r)), _ptr(saved_r), _ptr(_f32c(work_v)),
+                _ptr(_f32c(work_r)), _ptr(seam_err_v), _ptr(seam_err_r), _stream())
+        if cheap[0] or cheap[1]:
+            rc = load().icrl_chain_pair_fwd_seg_warm16(*head, int(cheap[0]), int(cheap[1]), int(phase), *tail)
+        else:
+            assert phase == 0
+            rc = load().icrl_chain_pair_fwd_seg(*head, *tail)
     _check(rc, "icrl_chain_pair_fwd_seg")
 
 

@@ -300,6 +300,24 @@ int icrl_chain_pair_fwd_seg(const float* xproj_v, const float* w_hh_v, const flo
                             float* saved_v, float* h_emit_r, float* saved_r, float* work_v, float* work_r,
                             float* seam_err_v, float* seam_err_r, icrl_stream_t stream);
 
+/* icrl_chain_pair_fwd_seg with the first cheap_v / cheap_r steps of each chain's warm-up (0 <= cheap < warmup)
+ * on the bf16 matrix instruction with both operands cut in two bf16 pieces (16 significant bits; the products
+ * hi.hi + hi.mid + mid.hi), a launch of its own before the float32 launch, which continues from the state it
+ * leaves.  A warm-up's results are discarded and the seam errors measure the state it ends in, exactly as
+ * without this; the float32 steps that remain (warmup - cheap; 16 or more in practice) wash the 2^-16 out.
+ * No counterpart in the reference: it shortens work that the segment-parallel evaluation of
+ * models.py:133, 226 adds.  The 16-bit launch holds every CU's registers while it runs, so a caller with work
+ * on other streams may want it to start only afterwards: phase 1 queues everything up to and including that
+ * launch, phase 2 (same arguments, same workspaces) the float32 launch and the seam checks; phase 0 both.
+ * icrl_chain_warm16_supported(segments): whether the 16-bit launch fits the device. */
+int icrl_chain_warm16_supported(int segments);
+int icrl_chain_pair_fwd_seg_warm16(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                   const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                                   int n_calls, int full_calls, int segments, int warmup_v, int warmup_r,
+                                   int cheap_v, int cheap_r, int phase, float* h_emit_v, float* saved_v,
+                                   float* h_emit_r, float* saved_r, float* work_v, float* work_r,
+                                   float* seam_err_v, float* seam_err_r, icrl_stream_t stream);
+
 /* The check that goes with full_calls < n_calls (no counterpart in the reference, which always replays):
  * for every call s >= full_calls, run the first `steps` positions of the replay that was left out, from the
  * state the chain had at the end of call s-1 (taken from saved_v / saved_r, the activations the forward

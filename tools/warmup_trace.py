@@ -42,6 +42,6 @@ for i in range(steps):
     s = engine.last_seam
     print("step %3d  W value fwd %4d (%.2f)  reward fwd %4d (%.2f)  value bwd %4d (%.2f)  redone %d  %6.2f ms" % (
         i, res.chain_plan[0][2], s[0] / engine.SEAM_TOL_FWD, res.reward_plan[2], s[2] / engine.SEAM_TOL_FWD,
-        res.chain_plan[1][2], (s[4] / s[5] if s[5] > 0 else 0.0) / engine.SEAM_TOL_BWD, engine.fallbacks - before, ms) + "  fc %d replay %s" % (res.full_calls, engine.last_replay),
+        res.chain_plan[1][2], (s[4] / s[5] if s[5] > 0 else 0.0) / engine.SEAM_TOL_BWD, engine.fallbacks - before, ms) + "  fc %d replay %s warm16 %s" % (res.full_calls, engine.last_replay, engine.last_cheap),
         flush=True)
 print("mean over steps 2.. : %.2f ms" % (total / max(1, steps - 2)))
