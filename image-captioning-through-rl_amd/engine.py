@@ -372,6 +372,13 @@ class A2CEngine:
     WARM16_MIN_WARMUP = 128   # shorter warm-ups gain nothing: the extra launch costs what its steps save
     WARM16_TAIL = 16   # float32 steps that end a warm-up whose first part ran at 16-bit precision (at least W / 8)
 
+    @staticmethod
+    def _sudden(ladder, idx, ok):
+        """Whether a seam check that failed (ok False) at ladder position idx came out of the blue: the last accepted
+        minibatch ran the same warm-up with its error under a quarter of the tolerance.  A failure that was
+        building up is the recurrence's memory growing, which is the ladder's business."""
+        return ok or (ladder.prev is not None and ladder.prev[0] == idx and ladder.prev[1] < 0.25)
+
     def _note_cheap(self, plan, plan_r):
         self.last_cheap = self._cheap_steps(plan[1], plan[2], plan_r[2])
         return self.last_cheap
@@ -848,7 +855,8 @@ class A2CEngine:
                         gave_up += 1
                         self.launch_timeouts += 1
                         continue
-                    if self._warm16_active(pv, pr) and not (self._ladder_fv.probing or self._ladder_fr.probing):
+                    if (self._warm16_active(pv, pr) and not (self._ladder_fv.probing or self._ladder_fr.probing)
+                            and self._sudden(self._ladder_fv, fv, ok_v) and self._sudden(self._ladder_fr, fr, ok_r)):
                         # the 16-bit part of the warm-up may be what failed (not so when a shorter warm-up was being
                         # tried: then that is what failed): the same plans again without it
                         self._warm16_off, self._warm16_penalty = self._warm16_penalty, min(2 * self._warm16_penalty, 1024)

@@ -1,7 +1,7 @@
 """Per-minibatch trace of the warm-up ladders on the bench workload: accepted warm-up lengths, seam errors
 as fractions of their tolerances, redone minibatches and step time.
 
-    python tools/warmup_trace.py [steps]
+    python tools/warmup_trace.py [steps] [first warm-up length]
 """
 import importlib
 import os
@@ -24,7 +24,7 @@ dev = torch.device("cuda", 0)
 n, vocab, caplen, fdim = 512, 10000, 20, 2048
 a2c, rew, flat, params = bench.build_networks(syn, models, optim, vocab, fdim, 0, dev)
 opt = optim.FusedAdam(flat, lr=1e-4)
-engine = trainers.build_engine(a2c, rew)
+engine = trainers.build_engine(a2c, rew, **({'first_warmup': int(sys.argv[2])} if len(sys.argv) > 2 else {}))
 feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, 0)
 fd, pd = torch.from_numpy(feats).to(dev), torch.from_numpy(caps[:, :1]).to(dev)
 u = torch.from_numpy(np.random.RandomState(1000).random_sample((steps, 19 * n))).to(dev)
