@@ -123,7 +123,7 @@ def plans_of(res, engine):
     fwd, bwd = res.chain_plan
     return {"forward": list(fwd), "reward_forward": list(res.reward_plan), "backward": list(bwd),
             "full_calls": res.full_calls, "replay_check": list(engine.last_replay) if engine.last_replay else None,
-            "warm16_steps": list(engine.last_cheap)}
+            "warm16_steps": list(engine.last_cheap), "warm16_steps_backward": engine.last_cheap_bwd}
 
 
 def main():

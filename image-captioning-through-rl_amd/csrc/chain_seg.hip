@@ -1196,6 +1196,8 @@ struct BwdArgs {
     float* dc; float* dgv; float* seam_a; float* dh_fin;
     unsigned* flags;          // [row tiles][32], 16 used
     Geom g;
+    int m_begin;              // first step walked here (0, or the steps seg_warm_bwd walked: dgx[(m_begin - 1) & 1] then
+                              // holds their last dgates and dc their carried dc)
 };
 
 struct FragB2 { float4 a0, a1; float b[8]; };
@@ -1265,12 +1267,14 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
     const int rr = tid >> 3, uq = 4 * (tid & 7);
     const int j = row0 + rr, u = u0 + uq;
     const bool have_row = j < g.K;
+    const int m0 = a.m_begin;
     float4 dcv = zero4();
+    if (m0 > 0 && have_row) dcv = ld4(a.dc + (int64_t)j * H + u);
     int ps = 0, pt = 0, pi = 0;
     float* tile = lds + w * TILE2;
 
     const int steps = g.W + g.Ls;
-    for (int mp = 0; mp <= steps; ++mp) {
+    for (int mp = m0; mp <= steps; ++mp) {   // flags count the steps walked here: mp - m0
         const bool final = mp == steps;
         const int cur = mp & 1;   // this step writes dgx[cur]; it reads dgx[cur ^ 1]
         const int qs = g.Ls + g.W - 1 - mp;   // step within the segment: >= Ls during the warm-up
@@ -1297,8 +1301,10 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
             for (int d = 0; d < PDEPTH; ++d)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ring_b[d][i] = B_LOAD(i, d);
+            // the first step walked here reads what an earlier launch left: nothing to wait for, and no flag
+            // has told yet where the row group's workgroups run
             if (w == 0) {
-                const bool l = wait_row_group(a.flags + by * 32, (unsigned)mp, abort_w, lane, xcd);
+                const bool l = mp > m0 && wait_row_group(a.flags + by * 32, (unsigned)(mp - m0), abort_w, lane, xcd);
                 if (lane == 0) *local_w = l;
             }
             __syncthreads();
@@ -1402,7 +1408,7 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
         __syncthreads();                                    // ... before ONE lane signals for all of them
         if (tid == 0 && !final) {
-            const unsigned word = (unsigned)(mp + 1) | (xcd << 24);
+            const unsigned word = (unsigned)(mp + 1 - m0) | (xcd << 24);
             gu32* fp = (gu32*)(a.flags + by * 32 + bx);
             if (local) __hip_atomic_store(fp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else __hip_atomic_store(fp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1411,6 +1417,237 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
 #undef WAVE_SYNC
 #undef A_LOAD
 #undef B_LOAD
+}
+
+// ------------------------------------------------------------------ the first steps of the backward warm-up, at 16-bit precision
+// The backward warm-up (the steps after a segment's last own position, walked down from a zero (dh, dc)) is
+// thrown away like the forward one: what matters is the (dh, dc) it leaves, and the backward seam check measures
+// that.  Its first steps run here with both operands of dh = dgates . W_hh cut in two bf16 pieces (the three
+// products hi.hi + hi.mid + mid.hi on the bf16 matrix instruction, 2^-16 relative error); seg_bwd_persist
+// continues from the dgates and dc left here (BwdArgs::m_begin).
+//
+// Workgroup (unit tile bx of 16 units, row group by of 32 segments); wave w takes the 512 gate rows of gate w as
+// its k range and keeps its 512 x 16 slice of W_hh for the whole launch: the hi pieces in registers (64 VGPRs),
+// the mid pieces in LDS (64 KB per workgroup, one 16-byte read per k step) - with both in registers the compiler
+// has no room left to keep more than four of a step's 64 operand loads in flight.
+// The dgates are exchanged ALREADY cut in two: every producer stores the hi and mid pieces of its 4 x 2 values
+// into two bf16 planes (the same bytes as float32 dgates), so a consumer loads matrix-instruction operands
+// straight from memory into registers - 16 bytes = 8 consecutive gate rows of one segment - with no LDS staging
+// and no barrier in the k loop; the four waves' partial tiles meet in LDS.  Hand-off as in seg_bwd_persist:
+// write-through stores, drained, one flag per workgroup and step, sc1 loads after the poll - and plain stores
+// once the XCD ids in the flags have shown that the row group's 32 workgroups share an XCD (the sc1 loads then
+// find the lines in that XCD's L2 instead of fetching 256 KB per workgroup and step through the fabric).
+// Planes of parity p, row group by: dgx + p * K * 4H floats + by * 32 * 4H floats, {hi[32][4H], mid[32][4H]} bf16 -
+// exactly the bytes of the row group's float32 rows dgx[p][32 by ..][4H], which the LAST step writes instead
+// (only the row group's own workgroups ever read those bytes, and the flags say they are done).  K % 32 == 0.
+struct WarmBwdArgs {
+    const float* w_hh; const float* saved; const float* d_emit;
+    float* dgx;               // [2][K][4H] floats: bf16 planes while the steps run, float32 dgates of the last step
+    float* dc;                // [K][H]: dc after the last step
+    unsigned* flags;          // [row groups][32]
+    Geom g;
+    int steps;                // steps mp = 0 .. steps - 1 of the chain's W + Ls + 1 are walked here (steps <= W)
+};
+
+// wave 0: lanes 0..31 each poll one producer's flag (step count in the low 24 bits, the producer's XCD above), lane 32
+// polls the abort word.  Returns whether all 32 producers run on XCD `xcd`.
+__device__ __forceinline__ bool wait_row_group32_xcd(unsigned* flags32, unsigned epoch, unsigned* abort_w, int lane,
+                                                     unsigned xcd) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        unsigned v = epoch | (xcd << 24), ab = 0;
+        if (lane < 32) v = __hip_atomic_load((gu32*)(flags32 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (lane == 32) ab = __hip_atomic_load((gu32*)abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__any(ab != 0)) return false;
+        if (__all((v & EPOCH_MASK) >= epoch)) return __all((v >> 24) == xcd);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__global__ __launch_bounds__(256, 1) void seg_warm_bwd(WarmBwdArgs a, unsigned* abort_w, int ny) {
+    __shared__ float gt[4 * 32 * WGT + 4];   // the four waves' partial [segment row][unit] tiles; one word for `local`
+    __shared__ __attribute__((aligned(16))) v4u wmid[4 * 16 * 64];   // [wave][k step][lane]: mid pieces of W_hh
+    __builtin_amdgcn_s_setprio(3);
+    // block b runs on XCD b % 8; a row group's 32 workgroups are given block ids of one XCD (speed only: whether
+    // they really share one is read from the flags)
+    const int wb = blockIdx.x, t = wb >> 3;
+    const int by = (t >> 5) * 8 + (wb & 7), bx = t & 31;
+    if (by >= ny) return;
+    const unsigned xcd = my_xcd();
+    int* local_w = reinterpret_cast<int*>(gt + 4 * 32 * WGT);
+    bool local = false;
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int row0 = by * 32, u0 = bx * 16;
+    const int parity_bytes = g.K * 4 * H * 4, group_bytes = by * 32 * 4 * H * 4;
+    constexpr int PLANE_BYTES = 32 * 4 * H * 2;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.dgx, 0, 2 * parity_bytes, 0x00020000);
+
+    // B operand of lane (column l15, k group kg) at k step ks: W_hh[gate row w H + 32 ks + 8 kg + 0..7][unit u0 + l15]
+    wbf16x8 bw[16];
+    v4u* wm = wmid + w * 16 * 64 + lane;
+    {
+        const float* wcol = a.w_hh + ((int64_t)w * H + 8 * kg) * H + u0 + l15;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            wbf16x8 bm;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 hi, mid;
+                split2(wcol[(int64_t)(32 * ks + e) * H], hi, mid);
+                bw[ks][e] = hi;
+                bm[e] = mid;
+            }
+            wm[ks * 64] = __builtin_bit_cast(v4u, bm);   // read back by this lane only
+        }
+    }
+    // A operand of lane (row l15, k group kg): 8 consecutive gate rows of segment row0 + 16 mt + l15, from a plane
+    const int a_voff = (l15 * 4 * H + w * H + 8 * kg) * 2;
+#define WB_LOAD(mt, plane, ks, base) \
+    __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff + ((mt) * 16 * 4 * H + 32 * (ks)) * 2 + (plane) * PLANE_BYTES, (base), SC1)
+
+    // this lane's epilogue item: segment row j, units u, u + 1; its dc lives in registers
+    const int rr = tid >> 3, uq = 2 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    const bool have_row = j < g.K;
+    float2 dcv = make_float2(0.f, 0.f);
+    int ps = 0, pt = 0, pi = 0;
+    const int st_voff = (rr * 4 * H + u) * 2;   // this item's place in a plane (+ gate * H)
+
+    for (int mp = 0; mp < a.steps; ++mp) {
+        const bool last = mp == a.steps - 1;
+        const int cur = mp & 1;   // this step writes parity cur; it reads parity cur ^ 1
+        const int qs = g.Ls + g.W - 1 - mp;   // >= Ls: every step here is a warm-up step
+        const int64_t pos = seg_pos(g, j, qs);
+        const bool live = have_row && pos < g.total && seg_pos(g, j, 0) < g.total;
+        const float2 z2 = make_float2(0.f, 0.f);
+        float2 gi = z2, gf = z2, gg = z2, go = z2, cc = z2, cp = z2, de = z2;
+        if (live) {
+            locate_fast(g, (int)pos, ps, pt, pi);
+            const float* sp = a.saved + pos * (6 * H) + u;
+#define LD2(p) (*reinterpret_cast<const float2*>(p))
+            gi = LD2(sp); gf = LD2(sp + H); gg = LD2(sp + 2 * H); go = LD2(sp + 3 * H); cc = LD2(sp + 4 * H);
+            if (pos >= g.stride) cp = LD2(a.saved + (pos - g.stride) * (6 * H) + 4 * H + u);
+            if (pt == g.p0 + ps - 1) de = LD2(a.d_emit + ((int64_t)ps * g.n + pi) * H + u);
+#undef LD2
+        }
+        f32x4 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] = 0.f;
+
+        if (mp > 0) {
+            if (w == 0) {
+                const bool l = wait_row_group32_xcd(a.flags + by * 32, (unsigned)mp, abort_w, lane, xcd);
+                if (lane == 0) *local_w = l;
+            }
+            __syncthreads();
+            local = *local_w != 0;
+            const int base = (cur ^ 1) * parity_bytes + group_bytes;
+            // batches of two k steps (8 loads of 16 bytes: 2 row tiles x 2 planes x 2 k steps), three in flight
+            constexpr int NB = 8, DEPTH = 3;
+            v4u ring[DEPTH][2][2][2];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) ring[d][kk][mt][pl] = WB_LOAD(mt, pl, 2 * d + kk, base);
+            // the scheduler would sink every load to its first use (four in flight instead of 24): nothing may
+            // cross the lines between a batch's matrix instructions and the loads that refill its slot
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int slot = b % DEPTH;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int ks = 2 * b + kk;
+                    const wbf16x8 bm = __builtin_bit_cast(wbf16x8, wm[ks * 64]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const wbf16x8 a_hi = __builtin_bit_cast(wbf16x8, ring[slot][kk][mt][0]);
+                        const wbf16x8 a_mid = __builtin_bit_cast(wbf16x8, ring[slot][kk][mt][1]);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bw[ks], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bm, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mid, bw[ks], acc[mt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (b + DEPTH < NB) {   // the slot is free again
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int pl = 0; pl < 2; ++pl)
+                                ring[slot][kk][mt][pl] = WB_LOAD(mt, pl, 2 * (b + DEPTH) + kk, base);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // accumulator register r of lane (l15, kg) is element [row 4 kg + r][column l15] of its 16 x 16 tile
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gt[(w * 32 + mt * 16 + 4 * kg + r) * WGT + l15] = acc[mt][r];
+        __syncthreads();
+
+        if (have_row) {
+            const float* pr = gt + rr * WGT + uq;
+            float2 dh = make_float2((pr[0] + pr[32 * WGT]) + (pr[64 * WGT] + pr[96 * WGT]),
+                                    (pr[1] + pr[32 * WGT + 1]) + (pr[64 * WGT + 1] + pr[96 * WGT + 1]));
+            float2 d_i = z2, d_f = z2, d_g = z2, d_o = z2, dcn = z2;
+            if (live) {
+                dh.x += de.x; dh.y += de.y;
+                LSTM_BWD1(x, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
+                LSTM_BWD1(y, dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
+            }
+            dcv = dcn;
+            if (last) {   // what the float32 launch continues from
+                float* dp = a.dgx + (int64_t)cur * g.K * 4 * H + (int64_t)j * 4 * H + u;
+                *reinterpret_cast<float2*>(dp) = d_i; *reinterpret_cast<float2*>(dp + H) = d_f;
+                *reinterpret_cast<float2*>(dp + 2 * H) = d_g; *reinterpret_cast<float2*>(dp + 3 * H) = d_o;
+                *reinterpret_cast<float2*>(a.dc + (int64_t)j * H + u) = dcv;
+            } else {
+                const int sb = cur * parity_bytes + group_bytes;
+                const float2 dv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    __bf16 hx, mx, hy, my;
+                    split2(dv[gq].x, hx, mx);
+                    split2(dv[gq].y, hy, my);
+                    if (local) {   // every reader shares this XCD's L2: no write-through needed
+                        __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(hx, hy), rs, st_voff + gq * H * 2, sb, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(mx, my), rs, st_voff + gq * H * 2 + PLANE_BYTES, sb, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(hx, hy), rs, st_voff + gq * H * 2, sb, SC1);
+                        __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(mx, my), rs, st_voff + gq * H * 2 + PLANE_BYTES, sb, SC1);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
+        __syncthreads();                                    // ... before ONE lane signals for all of them
+        if (tid == 0 && !last) {
+            const unsigned word = (unsigned)(mp + 1) | (xcd << 24);
+            gu32* fp = (gu32*)(a.flags + by * 32 + bx);
+            if (local) __hip_atomic_store(fp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_store(fp, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#undef WB_LOAD
 }
 
 __global__ void poison_on_abort1(const unsigned* abort_w, float* seam) {
@@ -1543,17 +1780,26 @@ int solo_persist(ChainArgs& a, int gates, float* work, hipStream_t st, unsigned*
     return ICRL_OK;
 }
 
-int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out) {
+// cheap: the first steps of the warm-up that run on seg_warm_bwd (16-bit split products) before the float32 launch
+int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, int cheap = 0) {
     const int K = a.g.K;
     const int64_t kh = (int64_t)K * H;
     const int ny = (K + 31) / 32;
     unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
-    // a 128-byte line of flags per row group: a line is then written from one XCD only when the group is XCD-local
-    const size_t word_bytes = ((size_t)(ny * 32 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    // a 128-byte line of flags per row group: a line is then written from one XCD only when the group is XCD-local;
+    // then the abort word, then the flags of the 16-bit launch
+    const size_t word_bytes = ((size_t)(2 * ny * 32 + 4) * sizeof(unsigned) + 255) / 256 * 256;
     ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
     ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
     a.dgx = work; a.dc = work + 8 * kh; a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
     *abort_out = words + ny * 32;
+    if (cheap > 0) {
+        WarmBwdArgs wa{};
+        wa.w_hh = a.w_hh; wa.saved = a.saved; wa.d_emit = a.d_emit; wa.dgx = a.dgx; wa.dc = a.dc;
+        wa.flags = words + ny * 32 + 4; wa.g = a.g; wa.steps = cheap;
+        hipLaunchKernelGGL(seg_warm_bwd, dim3((ny + 7) / 8 * 8 * 32), dim3(256), 0, st, wa, *abort_out, ny);
+        a.m_begin = cheap;
+    }
     hipLaunchKernelGGL(seg_bwd_persist, dim3(16 * ny), dim3(256), 0, st, a, *abort_out);
     return ICRL_OK;
 }
@@ -1832,27 +2078,63 @@ extern "C" int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w
     return ICRL_OK;
 }
 
-extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const float* d_emit, int N,
-                                               int p0, int n_calls, int full_calls, int segments, int warmup, float* dgates,
-                                               float* work, float* seam_err, icrl_stream_t stream) {
+namespace {
+int lstm_bwd_persist_impl(const char* who, const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                          int n_calls, int full_calls, int segments, int warmup, int cheap, float* dgates, float* work,
+                          float* seam_err, icrl_stream_t stream) {
     BwdArgs a{};
-    if (int rc = make_geom("icrl_lstm_chain_bwd_seg_persist", N, p0, n_calls, full_calls, segments, warmup, a.g)) return rc;
-    ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && seam_err, "icrl_lstm_chain_bwd_seg_persist: null pointer");
+    if (int rc = make_geom(who, N, p0, n_calls, full_calls, segments, warmup, a.g)) return rc;
+    ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && seam_err, "%s: null pointer", who);
     ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),
-                 "icrl_lstm_chain_bwd_seg_persist: buffers must be 16-byte aligned");
+                 "%s: buffers must be 16-byte aligned", who);
     ICRL_REQUIRE(icrl_chain_pair_supported(segments),
-                 "icrl_lstm_chain_bwd_seg_persist: %d segments need more workgroups than the device has CUs; its "
-                 "workgroups wait for each other and must all be resident", segments);
+                 "%s: %d segments need more workgroups than the device has CUs; its "
+                 "workgroups wait for each other and must all be resident", who, segments);
+    ICRL_REQUIRE(cheap >= 0 && cheap <= warmup, "%s: the 16-bit part of a warm-up cannot be longer than the warm-up", who);
+    ICRL_REQUIRE(cheap == 0 || icrl_chain_bwd_warm16_supported(segments),
+                 "%s: the 16-bit warm-up launch needs a multiple of 32 segments that fits the device (%d given)", who,
+                 segments);
     hipStream_t st = icrl::as_stream(stream);
     ICRL_HIP(hipMemsetAsync(seam_err, 0, 2 * sizeof(float), st));
     a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgv = dgates;
     unsigned* abort_w = nullptr;
-    if (int rc = bwd_persist(a, work, st, &abort_w)) return rc;
+    if (int rc = bwd_persist(a, work, st, &abort_w, cheap)) return rc;
     hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
                        a.g, seam_err, seam_err + 1);
     hipLaunchKernelGGL(poison_on_abort1, dim3(1), dim3(1), 0, st, abort_w, seam_err);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
+}
+}  // namespace
+
+extern "C" int icrl_chain_bwd_warm16_supported(int segments) {
+    // all 32 x ceil(segments / 32) workgroups of the 16-bit backward warm-up launch (rounded up to whole groups of
+    // 8 row groups) must be resident at once; its exchange layout needs whole row groups
+    static int cus = -1, per_cu = 0;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seg_warm_bwd, 256, 0) != hipSuccess) return 0;
+        cus = n;
+    }
+    if (segments < 32 || segments % 32 != 0) return 0;
+    const int ny = segments / 32;
+    return (ny + 7) / 8 * 8 * 32 <= cus * per_cu ? 1 : 0;
+}
+
+extern "C" int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const float* d_emit, int N,
+                                               int p0, int n_calls, int full_calls, int segments, int warmup, float* dgates,
+                                               float* work, float* seam_err, icrl_stream_t stream) {
+    return lstm_bwd_persist_impl("icrl_lstm_chain_bwd_seg_persist", w_hh, saved, d_emit, N, p0, n_calls, full_calls,
+                                 segments, warmup, 0, dgates, work, seam_err, stream);
+}
+
+extern "C" int icrl_lstm_chain_bwd_seg_warm16(const float* w_hh, const float* saved, const float* d_emit, int N,
+                                              int p0, int n_calls, int full_calls, int segments, int warmup, int cheap,
+                                              float* dgates, float* work, float* seam_err, icrl_stream_t stream) {
+    return lstm_bwd_persist_impl("icrl_lstm_chain_bwd_seg_warm16", w_hh, saved, d_emit, N, p0, n_calls, full_calls,
+                                 segments, warmup, cheap, dgates, work, seam_err, stream);
 }
 
 // ------------------------------------------------------------------ may the replays be left out?

@@ -182,7 +182,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
-                 frozen_reward=False, warm16=True,
+                 frozen_reward=False, warm16=True, warm16_backward=False,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -211,6 +211,12 @@ class A2CEngine:
         # the first part of the forward warm-ups at 16-bit split precision (see _cheap_steps)
         self.warm16, self._warm16_off, self._warm16_penalty = bool(warm16), 0, 32
         self.last_cheap = (0, 0)     # 16-bit warm-up steps (value, reward chain) of the last forward pair launch
+        self.last_cheap_bwd = 0      # 16-bit warm-up steps of the last value-chain BPTT launch
+        # off unless asked for: alone the 16-bit backward launch walks a warm-up step in 8.9 us against the float32
+        # launch's 11.5, but it holds every CU's registers, and inside the A2C step, where the policy network's
+        # backward pass shares the CUs with the chain, the step gets slower with it (soak 10.9 -> 12.7 ms)
+        self.warm16_backward = bool(warm16_backward)
+        self._warm16b_off, self._warm16b_penalty = 0, 32
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
         self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
         self.last_replay = None      # (full_calls, steps, err value chain, err reward chain) of the last step
@@ -397,6 +403,19 @@ class A2CEngine:
             return 0, 0
         cut = lambda w: max(0, w - max(self.WARM16_TAIL, w // 8))
         return cut(w_v), cut(w_r)
+
+    WARM16_BWD_TAIL = 8   # float32 steps that end a backward warm-up whose first part ran at 16-bit precision (at least W / 16)
+
+    def _cheap_bwd(self, plan):
+        """How many of the value chain's backward warm-up steps run at 16-bit split precision
+        (icrl_lstm_chain_bwd_seg_warm16) before the float32 launch.  The backward seam tolerance (1e-4 of the
+        largest state) is well above their 2^-16, so a short float32 tail is enough.  Switched off for a while
+        after a backward seam was rejected out of the blue with it in use."""
+        if (plan[0] != "segmented" or not self.warm16_backward or self._warm16b_off > 0
+                or plan[2] < self.WARM16_MIN_WARMUP
+                or not (self.persistent and hip.chain_pair_supported(plan[1]) and hip.chain_bwd_warm16_supported(plan[1]))):
+            return 0
+        return max(0, plan[2] - max(self.WARM16_BWD_TAIL, plan[2] // 16))
 
     def _replay_steps(self, w_fwd):
         """Steps of a left-out replay that the check walks: the longest forward warm-up in use (the seams say
@@ -904,8 +923,13 @@ class A2CEngine:
                     self._ladder_bwd.accepted(bi, checks_b, last)
                     break
                 self.fallbacks += 1
-                bi = self._next_rung(bi, checks_b)
-                self._ladder_bwd.rejected(bi)
+                if (self.last_cheap_bwd > 0 and not self._ladder_bwd.probing
+                        and self._sudden(self._ladder_bwd, bi, False)):
+                    # the 16-bit part of the warm-up may be what failed: the same plan again without it
+                    self._warm16b_off, self._warm16b_penalty = self._warm16b_penalty, min(2 * self._warm16b_penalty, 1024)
+                else:
+                    bi = self._next_rung(bi, checks_b)
+                    self._ladder_bwd.rejected(bi)
                 if self._choose(ws, n, p0, s, fv, fr, bi)[0] != fc:
                     restart = True     # the longer warm-up reaches further than the replays left out are long
                     break
@@ -917,6 +941,7 @@ class A2CEngine:
             break
         self._replay_accepted()
         self._warm16_off = max(0, self._warm16_off - 1)
+        self._warm16b_off = max(0, self._warm16b_off - 1)
         # the tensors handed back are final now; their copies queue behind the backward pass
         out = (tokT.t().contiguous(), ws["logp"].t().contiguous(), ws["values"].view(s, n).t().contiguous(),
                ws["rewards"].view(s, n).t().contiguous())
@@ -1178,9 +1203,11 @@ class A2CEngine:
                                     ws["work_v"], ws["status"][2:3],
                                     persistent=self.persistent and hip.chain_pair_supported(n))
         elif plan[0] == "segmented":
+            self.last_cheap_bwd = self._cheap_bwd(plan)
             hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
                                    dgv, ws["work_v"], ws["seam"][4:6], full_calls=fc,
-                                   persistent=self.persistent and hip.chain_pair_supported(plan[1]))
+                                   persistent=self.persistent and hip.chain_pair_supported(plan[1]),
+                                   cheap=self.last_cheap_bwd)
         else:
             assert fc == s
             hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,

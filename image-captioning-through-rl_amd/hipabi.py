@@ -41,6 +41,8 @@ SIGNATURES = {
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp] * 9),
     "icrl_chain_pair_fwd_seg_warm16": (c_int, [c_vp] * 5 + [c_int] * 11 + [c_vp] * 9),
     "icrl_chain_warm16_supported": (c_int, [c_int]),
+    "icrl_chain_bwd_warm16_supported": (c_int, [c_int]),
+    "icrl_lstm_chain_bwd_seg_warm16": (c_int, [c_vp] * 3 + [c_int] * 7 + [c_vp] * 4),
     "icrl_chain_pair_replay_check": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
     "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -683,15 +685,29 @@ def lstm_chain_bwd_rows(w_hh, saved, d_emit, n, p0, n_calls, dgates, work, statu
     _check(rc, "icrl_lstm_chain_bwd_rows")
 
 
+def chain_bwd_warm16_supported(segments):
+    return bool(load().icrl_chain_bwd_warm16_supported(int(segments)))
+
+
 def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False,
-                       full_calls=0):
+                       full_calls=0, cheap=0):
+    """cheap: the first steps of the warm-up that run at 16-bit split precision in a launch of their own
+    (icrl_lstm_chain_bwd_seg_warm16; persistent launches only)."""
     _chain_shapes("lstm_chain_bwd_seg", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit,
                   dgates=(dgates,), work=work, segments=segments, full_calls=full_calls)
-    fn = load().icrl_lstm_chain_bwd_seg_persist if persistent else load().icrl_lstm_chain_bwd_seg
-    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls, full_calls), steps=_seg_steps(n, p0, n_calls, full_calls, segments, warmup)):
-        rc = fn(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
-                                            n_calls, full_calls, segments, warmup, _ptr(_f32c(dgates)), _ptr(_f32c(work)),
-                                            _ptr(seam_err), _stream())
+    assert cheap == 0 or persistent, "the 16-bit warm-up belongs to the persistent launch"
+    steps = _seg_steps(n, p0, n_calls, full_calls, segments, warmup)
+    head = (_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls, full_calls, segments, warmup)
+    tail = (_ptr(_f32c(dgates)), _ptr(_f32c(work)), _ptr(seam_err), _stream())
+    # float32 matrix-instruction work: the steps that do not run at 16-bit split precision
+    with _Timed("lstm_chain_bwd", chain_positions(n, p0, n_calls, full_calls), steps=steps,
+                flops=2.0 * segments * 512 * 512 * 4 * (steps - cheap)):
+        if cheap:
+            rc = load().icrl_lstm_chain_bwd_seg_warm16(*head, int(cheap), *tail)
+        elif persistent:
+            rc = load().icrl_lstm_chain_bwd_seg_persist(*head, *tail)
+        else:
+            rc = load().icrl_lstm_chain_bwd_seg(*head, *tail)
     _check(rc, "icrl_lstm_chain_bwd_seg")
 
 

@@ -354,6 +354,19 @@ int icrl_lstm_chain_bwd_seg_persist(const float* w_hh, const float* saved, const
                                     int p0, int n_calls, int full_calls, int segments, int warmup, float* dgates,
                                     float* work, float* seam_err, icrl_stream_t stream);
 
+/* icrl_lstm_chain_bwd_seg_persist with the first `cheap` steps of the warm-up (0 <= cheap <= warmup) on the
+ * bf16 matrix instruction, both operands of dh = dgates . W_hh cut in two bf16 pieces (16 significant bits; the
+ * products hi.hi + hi.mid + mid.hi), in a launch of its own before the float32 launch, which continues from the
+ * dgates and dc it leaves.  The backward warm-up's results are discarded like the forward one's and seam_err
+ * measures the (dh, dc) it ends in, exactly as without this.  No counterpart in the reference: it shortens work
+ * that the segment-parallel evaluation of models.py:133's BPTT adds.  The exchanged dgates travel already cut
+ * in two (bf16 planes in the bytes of the float32 exchange buffers), so segments must be a multiple of 32;
+ * icrl_chain_bwd_warm16_supported(segments) says whether that holds and the 16-bit launch fits the device. */
+int icrl_chain_bwd_warm16_supported(int segments);
+int icrl_lstm_chain_bwd_seg_warm16(const float* w_hh, const float* saved, const float* d_emit, int N,
+                                   int p0, int n_calls, int full_calls, int segments, int warmup, int cheap,
+                                   float* dgates, float* work, float* seam_err, icrl_stream_t stream);
+
 /* out[(t*N+i), :] = sum over calls s that contain column t of dgates[pos(s,t,i), :] (positions of the
  * chain with `full_calls` calls in full; with full_calls = 1 and p0 = 1 every column occurs once) */
 int icrl_chain_fold_calls(const float* dgates, int N, int p0, int n_calls, int full_calls, int width, float* out,

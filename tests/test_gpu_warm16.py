@@ -1,6 +1,6 @@
-"""The first steps of the forward chains' warm-ups at 16-bit split precision (icrl_chain_pair_fwd_seg_warm16):
-a warm-up's results are discarded, so all that may change is the state it leaves, and that is measured by the
-same seam check.  Needs an MI355X: -m gpu."""
+"""The first steps of the chains' warm-ups at 16-bit split precision (icrl_chain_pair_fwd_seg_warm16 forward,
+icrl_lstm_chain_bwd_seg_warm16 backward): a warm-up's results are discarded, so all that may change is the state
+it leaves, and that is measured by the same seam check.  Needs an MI355X: -m gpu."""
 import importlib
 
 import numpy as np
@@ -72,6 +72,59 @@ def test_warm16_is_measured_by_the_seam_check():
         _pair(cheap=(48, 0), **kw)
 
 
+def _bwd(n, p0, s, k, fc, w_f, w_b, cheap, seed=0, scale=1.0):
+    """Value chain forward (float32, to have real activations), then its BPTT with `cheap` 16-bit warm-up steps."""
+    tv = hip.chain_positions(n, p0, s, fc)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u = lambda *shape, sc=1.0: ((torch.rand(*shape, generator=g) * 2 - 1) * sc).cuda()
+    w_hv = u(4 * H, H, sc=scale * H ** -0.5)
+    xp_v = u((p0 + s - 1) * n, 4 * H)
+    d_emit = u(s, n, H, sc=1e-3)
+    hv, saved = torch.zeros(s, n, H, device="cuda"), torch.zeros(tv, 6, H, device="cuda")
+    work = torch.zeros(hip.chain_seg_workspace_floats(k), device="cuda")
+    seam = torch.zeros(4, device="cuda")
+    hip.lstm_chain_fwd_seg(xp_v, w_hv, n, p0, s, k, w_f, hv, saved, work, seam[0:2], persistent=True, full_calls=fc)
+    dgv = torch.zeros(tv, 4 * H, device="cuda")
+    hip.lstm_chain_bwd_seg(w_hv, saved, d_emit, n, p0, s, k, w_b, dgv, work, seam[2:4], persistent=True, full_calls=fc,
+                           cheap=cheap)
+    torch.cuda.synchronize()
+    return dgv, seam.tolist()
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=512, p0=1, s=19, k=256, fc=1, w_f=96, w_b=96, cheap=80),     # the A2C minibatch, replays left out
+    dict(n=512, p0=1, s=19, k=256, fc=1, w_f=96, w_b=192, cheap=192),   # the whole warm-up at 16 bits
+    dict(n=64, p0=2, s=10, k=64, fc=0, w_f=128, w_b=128, cheap=100),    # every call in full, two row groups
+    dict(n=40, p0=1, s=12, k=96, fc=2, w_f=64, w_b=64, cheap=1),        # the shortest 16-bit part
+    dict(n=40, p0=1, s=12, k=96, fc=2, w_f=64, w_b=64, cheap=2),
+])
+def test_backward_warm16_leaves_the_state_the_float32_warm_up_leaves(case):
+    if not (hip.chain_pair_supported(case["k"]) and hip.chain_bwd_warm16_supported(case["k"])):
+        pytest.skip("the persistent launches do not fit this device")
+    c = dict(case)
+    cheap = c.pop("cheap")
+    want, seam_w = _bwd(cheap=0, **c)
+    got, seam_g = _bwd(cheap=cheap, **c)
+    assert seam_w[2] <= 1e-4 * seam_w[3] and seam_g[2] <= 1e-4 * seam_g[3], (seam_w, seam_g)
+    # the segments' own positions are walked in float32 from a (dh, dc) that differs by what the seam allows
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert float((got - want).norm()) <= 2e-5 * float(want.norm())
+
+
+def test_backward_warm16_is_measured_by_the_seam_check_and_needs_whole_row_groups():
+    if not hip.chain_bwd_warm16_supported(128):
+        pytest.skip("the persistent launches do not fit this device")
+    kw = dict(n=256, p0=1, s=19, k=128, fc=1, w_f=512, w_b=16, scale=3.0)   # a long memory, a short backward warm-up
+    _, plain = _bwd(cheap=0, **kw)
+    _, mixed = _bwd(cheap=12, **kw)
+    assert plain[2] > 1e-4 * plain[3] and mixed[2] > 1e-4 * mixed[3]      # too short: rejected either way
+    assert not hip.chain_bwd_warm16_supported(80)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        _bwd(n=40, p0=1, s=12, k=80, fc=2, w_f=64, w_b=64, cheap=8)
+    with pytest.raises(RuntimeError, match="longer than the warm-up"):
+        _bwd(n=40, p0=1, s=12, k=96, fc=2, w_f=64, w_b=64, cheap=65)
+
+
 def test_engine_uses_warm16_from_128_warm_up_steps_and_gets_the_same_minibatch():
     cfg = dict(n=512, vocab=1000, caplen=20, fdim=512, seed=3, level=None)
     w2i = synthetic.make_word_to_idx(cfg["vocab"])
@@ -86,16 +139,19 @@ def test_engine_uses_warm16_from_128_warm_up_steps_and_gets_the_same_minibatch()
     u = torch.from_numpy(synthetic.make_uniforms(cfg["seed"], 19 * cfg["n"])).cuda()
     args = (torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :1]).cuda(), 19)
     out = {}
-    for warm16 in (True, False):
-        engine = trainers.build_engine(a2c, nets[2], first_warmup=128, warm16=warm16)
+    for warm16 in (True, False, "backward too"):
+        engine = trainers.build_engine(a2c, nets[2], first_warmup=128, warm16=bool(warm16),
+                                       warm16_backward=warm16 == "backward too")
         res = engine.step(*args, uniforms=u).check()
         torch.cuda.synchronize()
         assert res.chain_plan[0][:1] == ("segmented",) and res.chain_plan[0][2] >= 128
-        assert (engine.last_cheap[0] > 0) == warm16 and engine.fallbacks == 0
+        assert (engine.last_cheap[0] > 0) == bool(warm16) and engine.fallbacks == 0
+        assert (engine.last_cheap_bwd > 0) == (warm16 == "backward too")   # the backward launch only when asked for
         out[warm16] = (res.tokens.clone(), res.values.clone(), res.rewards.clone(),
                        {k: p.grad.clone() for k, p in a2c.named_parameters()})
-    assert torch.equal(out[True][0], out[False][0])
-    for a, b in zip(out[True][1:3], out[False][1:3]):
-        assert float((a - b).abs().max()) <= 1e-5
-    for k, g in out[False][3].items():
-        assert float((out[True][3][k] - g).norm()) <= 1e-4 * float(g.norm()) + 1e-9, k
+    for variant in (True, "backward too"):
+        assert torch.equal(out[variant][0], out[False][0])
+        for a, b in zip(out[variant][1:3], out[False][1:3]):
+            assert float((a - b).abs().max()) <= 1e-5
+        for k, g in out[False][3].items():
+            assert float((out[variant][3][k] - g).norm()) <= 1e-4 * float(g.norm()) + 1e-9, k

@@ -1,6 +1,7 @@
 """Time the segment-parallel chain kernels alone and side by side (us per step launch).
 
     python tools/chain_bench.py [segments] [warmup] [full_calls: 0 = every call in full, 1 = replays left out]
+                                [cheap: warm-up steps at 16-bit split precision]
 """
 import importlib
 import os
@@ -16,6 +17,7 @@ n, p0, s = 512, 1, 19
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 FC = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+CHEAP = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = "cuda"
 tv = hip.chain_positions(n, p0, s, FC)
 tr = hip.chain_positions(n, p0 + 1, s, FC)
@@ -109,6 +111,17 @@ if hip.chain_pair_supported(K):
     bwd_v(); torch.cuda.synchronize()
     print("bwd persistent == per-step:", torch.equal(dgv, dgv2), seam3.tolist(), float((dgv - dgv2).abs().max()))
 print("seam", seam.tolist())
+if CHEAP and hip.chain_bwd_warm16_supported(K) and hip.chain_warm16_supported(K):
+    seam4 = torch.zeros(6, device=dev)
+    timeit("fwd pair, %d steps at 16 bits" % CHEAP,
+           lambda: hip.chain_pair_fwd_seg(xp_v, w_v, xp_r, w_r, b_r, n, p0, p0 + 1, s, K, W, hv2, saved2, hr2, work_v, work_r,
+                                          seam4[0:1], seam4[2:3], full_calls=FC, cheap=(CHEAP, CHEAP)), max(steps_v, steps_r))
+    dgv5 = torch.empty_like(dgv)
+    timeit("lstm bwd, %d steps at 16 bits" % CHEAP,
+           lambda: hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv5, work_v, seam4[4:6], persistent=True,
+                                          full_calls=FC, cheap=CHEAP), steps_v + 1)
+    print("seam with 16-bit parts", seam4.tolist(), "max |dgv - float32 run|", float((dgv5 - dgv).abs().max()),
+          "of", float(dgv.abs().max()))
 if hip.chain_pair_supported(K):
     dgv3 = torch.empty_like(dgv)
     hip.lstm_chain_bwd_seg(w_v, saved, d_emit, n, p0, s, K, W, dgv3, work_v, seam3, persistent=True, full_calls=FC)
