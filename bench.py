@@ -15,7 +15,8 @@ Beside the K timed steps the line carries
     memory - hence the chains' warm-up - grows with it): mean / p95 step time, the plans it ended on and
     how many minibatches had to be redone;
   * `roofline`: the f32 MFMA GEMM launches of one timed step (HIP events around every launch, on the stream
-    it is launched on), FLOPs / time against the f32 MFMA peak;
+    it is launched on), FLOPs / time against the f32 MFMA peak; `roofline.one_stream`: the same launches of one
+    more minibatch run on ONE stream, with nothing beside them;
   * `chains`: the recurrent-chain launches of the same step with the steps they walked, their MFMA work as
     executed (warm-up included) and as the reference's chains would need;
   * `cpu_baseline`: the reference-shaped float32 CPU port timed on this host (rank 0, N = 1 only).
@@ -184,7 +185,7 @@ def main():
     feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, rank)  # a different shard per rank
     feats_d = torch.from_numpy(feats).to(dev)
     prefix_d = torch.from_numpy(caps[:, :1]).to(dev)
-    total_steps = args.warmup + args.steps + args.soak
+    total_steps = args.warmup + args.steps + args.soak + 2
     uniforms = torch.from_numpy(
         np.random.RandomState(1000 + rank).random_sample((total_steps, steps_per_rollout * n))).to(dev)
 
@@ -245,6 +246,29 @@ def main():
                 "ms_per_step_max": 1e3 * float(np.max(times)), "images_per_s": world * n / worst,
                 "redone_minibatches": engine.fallbacks - before, "final_plans": plans_of(res_s, engine),
                 "note": "each minibatch synchronised and timed on the host; the same networks keep training"}
+
+    # ---- the same launches with nothing beside them: one more minibatch with every launch on ONE stream, each
+    # bracketed by HIP events.  In the timed steps the GEMM launches share the CUs with the chain kernels and
+    # with each other (three streams), so their durations there say how the step is packed, not how good the
+    # kernel is; this pass gives the kernel's own figure for the very same shapes.
+    one_stream = None
+    if world == 1:
+        engine.concurrent = False
+        one_step(total_steps - 2)
+        torch.cuda.synchronize()
+        hip.PROFILE = []
+        one_step(total_steps - 1)
+        torch.cuda.synchronize()
+        alone, hip.PROFILE = hip.PROFILE, None
+        engine.concurrent = True
+        fl = sum(r[1] for r in alone if r[0] == "gemm")
+        se = sum(r[2].elapsed_time(r[3]) for r in alone if r[0] == "gemm") * 1e-3
+        if se > 0:
+            one_stream = {"achieved": fl / se / 1e12, "frac": fl / se / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                          "launches": sum(1 for r in alone if r[0] == "gemm"), "gflop": fl / 1e9,
+                          "ms_in_kernel": 1e3 * se,
+                          "note": "the step's gemm_f32_kernel launches with every launch of the minibatch on one "
+                                  "stream (nothing runs beside them), HIP events around each"}
 
     # ---- per-kernel accounting of the profiled step from the HIP events recorded on each launch's own stream
     acc, chain_steps, chain_flops = {}, {}, {}
@@ -341,6 +365,7 @@ def main():
                                    "chain input projections and weight gradients)",
                          "launches_per_step": gemm_launches, "gflop_per_step": gemm_flops / 1e9,
                          "ms_per_step_in_kernel": 1e3 * gemm_s,
+                         "one_stream": one_stream,
                          "events": "HIP events around every launch of the first of the timed steps, on its own stream",
                          "mfma_utilisation_pmc": mfma_util,
                          "mfma_profile_git_sha": (pmc_m or {}).get("_git_sha"),
