@@ -223,6 +223,7 @@ class A2CEngine:
         self.launch_timeouts = 0     # attempts repeated because a persistent launch gave up waiting for a workgroup
         self._check = None           # third stream: the replay check runs beside the backward pass
         self.trace = None  # set to [] to collect (label, stream-name, event) marks for phase timing
+        self.host_trace = None  # set to [] beside it to collect (label, host clock) at the same points
         # on_policy_grads(event): called once per step as soon as the forward pass has been accepted, with
         # the event after which the policy network's gradients are complete; a data-parallel caller starts
         # their all-reduce there, beside the value chain's BPTT
@@ -486,6 +487,9 @@ class A2CEngine:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream())
             self.trace.append((label, ev))
+            if self.host_trace is not None:   # when the HOST got here (it queues ahead of the device, or falls behind)
+                import time
+                self.host_trace.append((label, time.perf_counter()))
 
     def _side_stream(self):
         """A second stream that really runs beside the current one.  HIP multiplexes its streams onto a
@@ -1310,14 +1314,10 @@ class A2CEngine:
             if other is not cur:
                 self._mark("check:vocab_grads_done")
         dgp = ws["dgp"]
-        dc = [ws["dc0"], ws["dc1"]]
-        for k in range(t_steps - 1, -1, -1):
-            hip.lstm_cell_bwd(ws["gates"][k], ws["Cbuf"][k], ws["Cbuf"][k + 1], dHall[k],
-                              None if k == t_steps - 1 else dc[(k + 1) & 1], dgp[k], dc[k & 1])
-            if k > 0:
-                hip.gemm_auto(dgp[k], P["lstm.weight_hh_l0"], dHall[k - 1], ss, b_kmajor=True, accumulate=True, shared=True, dtype=self.pd)
-            else:
-                hip.gemm_auto(dgp[0], P["lstm.weight_hh_l0"], ws["dh0"], ss, b_kmajor=True, shared=True, dtype=self.pd)
+        # the LSTM's backward-through-time: 3 launches per step, queued by the library in one call (from Python the
+        # 57 launches of a 19-step rollout cost about half a millisecond of host time)
+        hip.policy_lstm_bptt(ws["gates"], ws["Cbuf"], dHall, P["lstm.weight_hh_l0"], dgp, ws["dc0"], ws["dc1"], ws["dh0"],
+                             ss, shared=True, dtype=self.pd)
         dg_all = dgp.view(t_steps * n, 4 * H)
         hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "icrl_lstm_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_gru_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "icrl_policy_lstm_bptt": (c_int, [c_vp] * 9 + [c_i64] + [c_int] * 5 + [c_vp]),
     "icrl_policy_lstm_step": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                       c_vp]),
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
@@ -171,8 +172,19 @@ def _ptr(t):
 STREAM = None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream if STREAM is None else STREAM
+    """Handle of the stream launches go to.  torch.cuda.current_stream() builds a Stream object through several
+    Python layers (a few microseconds, on each of a minibatch's ~200 launches); the raw accessors behind it
+    return the same handle in a fraction of that."""
+    if STREAM is not None:
+        return STREAM
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _check(rc, what):
@@ -483,7 +495,18 @@ def sum_slabs(slabs, out, accumulate=False):
            "icrl_sum_slabs")
 
 
+_PLANS = {}
+
+
 def plan_gemm(m, n, k, out_contiguous=True, shared=False):
+    key = (m, n, k, out_contiguous, shared)
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _PLANS[key] = _plan_gemm(m, n, k, out_contiguous, shared)
+    return plan
+
+
+def _plan_gemm(m, n, k, out_contiguous=True, shared=False):
     """(tile, splits) for an [m,n,k] product, from measurements on MI355X (tools/gemm_sweep.py).
     shared: the launch will run beside a persistent chain kernel that holds half of every CU's LDS and
     registers; two 64x64-tile workgroups still fit beside it on a CU, one of the larger tiles at most, so
@@ -709,6 +732,29 @@ def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dg
         else:
             rc = load().icrl_lstm_chain_bwd_seg(*head, *tail)
     _check(rc, "icrl_lstm_chain_bwd_seg")
+
+
+def policy_lstm_bptt(gates_act, c_all, d_h, w_hh, dgates, dc0, dc1, dh0, scratch, *, shared=False, dtype="f32"):
+    """Backward-through-time of the policy LSTM over all T steps in one call (see icrl_policy_lstm_bptt);
+    the products' tile / split-K plan is plan_gemm's, as for gemm_auto."""
+    t_steps, n = gates_act.shape[0], gates_act.shape[1]
+    assert gates_act.shape == (t_steps, n, 2048) and c_all.shape[0] >= t_steps + 1 and c_all.shape[1:] == (n, 512)
+    assert d_h.shape == (t_steps, n, 512) and dgates.shape == (t_steps, n, 2048) and w_hh.shape == (2048, 512)
+    for t in (dc0, dc1, dh0):
+        assert t.shape == (n, 512)
+    tile, splits = plan_gemm(n, 512, 2048, True, shared)
+    if splits > 1:
+        splits = max(1, min(splits, scratch.numel() // (n * 512)))
+    if dtype == "bf16" and tile == 2:
+        tile = 1
+    # one timing record for the whole sequence, under a kind of its own: it holds the cell kernels and the slab
+    # sums beside the T products of 2 N 512 2048 FLOPs each
+    with _Timed("policy_bptt", t_steps, steps=t_steps, flops=2.0 * t_steps * n * 512 * 2048):
+        rc = load().icrl_policy_lstm_bptt(_ptr(_f32c(gates_act)), _ptr(_f32c(c_all)), _ptr(_f32c(d_h)), _ptr(_f32c(w_hh)),
+                                          _ptr(_f32c(dgates)), _ptr(_f32c(dc0)), _ptr(_f32c(dc1)), _ptr(_f32c(dh0)),
+                                          _ptr(_f32c(scratch)), scratch.numel(), n, t_steps, splits, int(tile),
+                                          int(dtype == "bf16"), _stream())
+    _check(rc, "icrl_policy_lstm_bptt")
 
 
 def policy_lstm_step(emb, tokens, w_ih, w_hh, b_ih, b_hh, h_cur, c_cur, gates_act, c_next, h_next, x_out=None):

@@ -131,6 +131,20 @@ int icrl_lstm_cell_bwd(const float* gates_act, const float* c_prev, const float*
                        const float* dh, const float* dc, float* dgates, float* dc_prev, int N,
                        icrl_stream_t stream);
 
+/* The policy LSTM's backward-through-time over the T steps of a rollout (autograd of models.py:80,
+ * trainers.py:479) as one call: for k = T-1 .. 0, icrl_lstm_cell_bwd on step k (gates_act [T,N,4H], c_all
+ * [T+1,N,H] = the cell state before step 0 and after every step, dH [T,N,H] = the gradient that reaches each
+ * step's output from the vocabulary projection), then dH[k-1] += dgates[k] . W_hh, and for k = 0
+ * dh0 = dgates[0] . W_hh (the gradient of the state the image features initialise).  dgates [T,N,4H] is
+ * written for the weight-gradient products; dc0 / dc1 [N,H] carry the cell-state gradient.  The products run
+ * as icrl_gemm_f32_splitk + icrl_sum_slabs (splits > 1; scratch >= splits*N*512 floats) or icrl_gemm_f32, the
+ * bf16 variants if bf16 != 0: the same launches in the same order as a caller issuing them one by one, queued
+ * without a Python host's per-launch cost. */
+int icrl_policy_lstm_bptt(const float* gates_act, const float* c_all, float* dH, const float* w_hh,
+                          float* dgates, float* dc0, float* dc1, float* dh0, float* scratch,
+                          int64_t scratch_floats, int N, int T, int splits, int tile, int bf16,
+                          icrl_stream_t stream);
+
 /* One whole step of the policy LSTM in a single launch (models.py:73 + :80 for one position):
  * x = emb[tokens[i]], gates = x*W_ih^T + h_cur*W_hh^T + b_ih + b_hh, then the cell.  Writes the
  * activated gates [N,4H] (for the backward pass), c_next, h_next and, if x_out is given, the

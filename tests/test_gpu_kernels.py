@@ -662,3 +662,58 @@ def test_sampler_with_next_cell_update(mode):
     np.testing.assert_allclose(gates.cpu().numpy(), torch.cat((i, f, g, o), 1).numpy(), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(c_out.cpu().numpy(), c.numpy(), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(h_out.cpu().numpy(), h.numpy(), rtol=2e-6, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- policy LSTM backward-through-time
+@pytest.mark.parametrize("n,t_steps,dtype", [(512, 19, "f32"), (48, 5, "f32"), (64, 3, "bf16")])
+def test_policy_lstm_bptt_equals_the_launches_issued_one_by_one_and_autograd(n, t_steps, dtype):
+    """icrl_policy_lstm_bptt queues cell backward + dgates . W_hh per step itself: bit for bit what the same
+    launches give when issued one by one, and (float32) the gradients autograd gives for models.py:80."""
+    rs = np.random.RandomState(5)
+    w_hh = dev(rnd(rs, 4 * H, H, scale=H ** -0.5))
+    xw = rnd(rs, t_steps, n, 4 * H)                   # the input side of every step's gates, held fixed
+    c_all = torch.zeros(t_steps + 1, n, H, device="cuda")
+    h_all = torch.zeros(t_steps + 1, n, H, device="cuda")
+    c_all[0], h_all[0] = dev(rnd(rs, n, H)), dev(rnd(rs, n, H))
+    gates = torch.empty(t_steps, n, 4 * H, device="cuda")
+    for k in range(t_steps):                          # forward with the kernels, keeping what the backward pass reads
+        gates[k] = dev(xw[k])
+        hip.gemm(h_all[k], w_hh, gates[k], accumulate=True)
+        hip.lstm_cell_fwd(gates[k], c_all[k], c_all[k + 1], h_all[k + 1])
+    d_out = dev(rnd(rs, t_steps, n, H, scale=0.1))    # gradient reaching every step's output h
+    scratch = torch.empty(16 * n * H, device="cuda")
+
+    def one_by_one():
+        d_h, dgp = d_out.clone(), torch.empty(t_steps, n, 4 * H, device="cuda")
+        dc, dh0 = [torch.empty(n, H, device="cuda") for _ in range(2)], torch.empty(n, H, device="cuda")
+        for k in range(t_steps - 1, -1, -1):
+            hip.lstm_cell_bwd(gates[k], c_all[k], c_all[k + 1], d_h[k], None if k == t_steps - 1 else dc[(k + 1) & 1],
+                              dgp[k], dc[k & 1])
+            out = d_h[k - 1] if k > 0 else dh0
+            hip.gemm_auto(dgp[k], w_hh, out, scratch, b_kmajor=True, accumulate=k > 0, shared=True, dtype=dtype)
+        return dgp, dh0, dc[0]
+
+    d_h, dgp = d_out.clone(), torch.empty(t_steps, n, 4 * H, device="cuda")
+    dc0, dc1, dh0 = (torch.empty(n, H, device="cuda") for _ in range(3))
+    hip.policy_lstm_bptt(gates, c_all, d_h, w_hh, dgp, dc0, dc1, dh0, scratch, shared=True, dtype=dtype)
+    want = one_by_one()
+    torch.cuda.synchronize()
+    assert torch.equal(dgp, want[0]) and torch.equal(dh0, want[1]) and torch.equal(dc0, want[2])
+    if dtype != "f32":
+        return
+    # autograd on the CPU over the same recurrence
+    w = w_hh.cpu().double().requires_grad_(True)
+    h = h_all[0].cpu().double().requires_grad_(True)
+    c = c_all[0].cpu().double().requires_grad_(True)
+    h0, c0, loss = h, c, 0.0
+    for k in range(t_steps):
+        g = torch.from_numpy(xw[k]).double() + h @ w.t()
+        i, f, gg, o = g.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        loss = loss + (h * d_out[k].cpu().double()).sum()
+    loss.backward()
+    np.testing.assert_allclose(dh0.cpu().numpy(), h0.grad.numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(dc0.cpu().numpy(), c0.grad.numpy(), rtol=2e-4, atol=2e-6)
+    dw = (dgp.view(-1, 4 * H).cpu().double().t() @ h_all[:t_steps].reshape(-1, H).cpu().double())
+    np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), rtol=2e-4, atol=2e-5)

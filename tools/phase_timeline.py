@@ -18,12 +18,14 @@ fd = torch.from_numpy(feats).to(dev); pd = torch.from_numpy(caps[:, :1]).to(dev)
 u = torch.from_numpy(np.random.RandomState(1).random_sample((6, 19 * n))).to(dev)
 import time
 for i in range(6):
-    if i == 5: engine.trace = []
+    if i == 5: engine.trace, engine.host_trace = [], []
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = engine.step(fd, pd, 19, uniforms=u[i]); t1 = time.perf_counter()
     opt.step(); res.check(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("step %d: host enqueue+seam sync %.2f ms, total %.2f ms, plan %s, fallbacks %d" % (i, 1e3 * (t1 - t0), 1e3 * (t2 - t0), res.chain_plan, engine.fallbacks))
 tr = engine.trace
 t0 = tr[0][1]
-for label, ev in tr:
-    print("%-28s %8.2f ms" % (label, t0.elapsed_time(ev)))
+h0 = engine.host_trace[0][1]
+print("%-28s %11s %14s" % ("", "device", "host got there"))
+for (label, ev), (_, h) in zip(tr, engine.host_trace):
+    print("%-28s %8.2f ms %11.2f ms" % (label, t0.elapsed_time(ev), 1e3 * (h - h0)))
