@@ -45,7 +45,10 @@ struct NextCell {
     float* h_out;
 };
 
-template <int MODE>
+// DL: the `probs` output receives onehot(token) - softmax instead of the softmax (what the policy's backward pass
+// needs, up to the per-row coefficient dLoss / dlog_prob): -p from every thread in pass 3, and the thread that
+// wrote the token's entry corrects it to 1 - p once the token is fixed (same thread, same address: ordered).
+template <int MODE, bool DL>
 __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int64_t ld, int V,
                                                      const double* __restrict__ uniforms,
                                                      int64_t* __restrict__ tokens, int64_t token_stride,
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             float4 p = row4[k];
             p.x /= s; p.y /= s; p.z /= s; p.w /= s;
             row4[k] = p;
-            if (out4) out4[k] = p;
+            if (out4) out4[k] = DL ? make_float4(0.f - p.x, 0.f - p.y, 0.f - p.z, 0.f - p.w) : p;
             if (entropy) {
                 if (p.x > 0.f) ent -= p.x * logf(p.x);
                 if (p.y > 0.f) ent -= p.y * logf(p.y);
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         for (int k = tid; k < V; k += 256) {
             const float p = row[k] / s;
             row[k] = p;
-            if (probs) probs[(int64_t)r * V + k] = p;
+            if (probs) probs[(int64_t)r * V + k] = DL ? 0.f - p : p;
             if (entropy && p > 0.f) ent -= p * logf(p);
         }
     }
@@ -202,6 +205,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const bool ok = token >= 0 && token < V;
         log_prob[r * lp_stride] = ok ? logf(row[token]) : NAN;
     }
+    if (DL && probs && token >= 0 && token < V && tid == (vec ? (token >> 2) & 255 : token & 255))
+        probs[(int64_t)r * V + token] = 1.f - row[token];
     if (cell.pre != nullptr && token >= 0 && token < V) {
         // gates = h . W_hh^T + (W_ih x + b) for the token just fixed, then the cell (models.py:80): two units a lane
         const float* pr = cell.pre + (int64_t)r * cell.ld_pre;
@@ -280,23 +285,27 @@ int launch_sampler(const float* logits, int64_t ld_logits, int N, int V, int mod
     hipStream_t st = icrl::as_stream(stream);
     const size_t lds = (size_t)V * sizeof(float);
     dim3 grid(N), block(256);
+    const bool dl = (mode & ICRL_EMIT_DLOGITS) != 0;
+    mode &= ~ICRL_EMIT_DLOGITS;
+#define ICRL_SAMPLER_LAUNCH(M, D, LDS)                                                                              \
+    hipLaunchKernelGGL((sample_kernel<M, D>), grid, block, LDS, st, logits, ld_logits, V, uniforms, tokens_out,     \
+                       token_stride, log_prob, log_prob_stride, probs, entropy, cell)
     switch (mode) {
         case ICRL_SAMPLE:
-            hipLaunchKernelGGL(sample_kernel<ICRL_SAMPLE>, grid, block, lds, st, logits, ld_logits, V, uniforms,
-                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy, cell);
+            if (dl) ICRL_SAMPLER_LAUNCH(ICRL_SAMPLE, true, lds); else ICRL_SAMPLER_LAUNCH(ICRL_SAMPLE, false, lds);
             break;
         case ICRL_GREEDY:
-            hipLaunchKernelGGL(sample_kernel<ICRL_GREEDY>, grid, block, 0, st, logits, ld_logits, V, uniforms,
-                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy, cell);
+            if (dl) { icrl::set_error("icrl_sample_tokens: ICRL_EMIT_DLOGITS needs ICRL_SAMPLE or ICRL_FORCED"); return ICRL_ERR_ARG; }
+            ICRL_SAMPLER_LAUNCH(ICRL_GREEDY, false, 0);
             break;
         case ICRL_FORCED:
-            hipLaunchKernelGGL(sample_kernel<ICRL_FORCED>, grid, block, lds, st, logits, ld_logits, V, uniforms,
-                               tokens_out, token_stride, log_prob, log_prob_stride, probs, entropy, cell);
+            if (dl) ICRL_SAMPLER_LAUNCH(ICRL_FORCED, true, lds); else ICRL_SAMPLER_LAUNCH(ICRL_FORCED, false, lds);
             break;
         default:
             icrl::set_error("icrl_sample_tokens: unknown mode %d", mode);
             return ICRL_ERR_ARG;
     }
+#undef ICRL_SAMPLER_LAUNCH
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -309,7 +318,8 @@ extern "C" int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N,
     ICRL_REQUIRE(logits && tokens_out && N > 0 && V > 0, "icrl_sample_tokens: null pointer or empty shape");
     ICRL_REQUIRE(ld_logits >= V, "icrl_sample_tokens: ld_logits < V");
     ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_sample_tokens: vocabulary %d exceeds the 16384-entry LDS row", V);
-    ICRL_REQUIRE(mode != ICRL_SAMPLE || uniforms, "icrl_sample_tokens: ICRL_SAMPLE needs uniforms");
+    ICRL_REQUIRE((mode & ~ICRL_EMIT_DLOGITS) != ICRL_SAMPLE || uniforms, "icrl_sample_tokens: ICRL_SAMPLE needs uniforms");
+    ICRL_REQUIRE(!(mode & ICRL_EMIT_DLOGITS) || probs, "icrl_sample_tokens: ICRL_EMIT_DLOGITS needs the probs output");
     return launch_sampler(logits, ld_logits, N, V, mode, uniforms, tokens_out, token_stride, log_prob, log_prob_stride,
                           probs, entropy, NextCell{}, stream);
 }
@@ -322,8 +332,10 @@ extern "C" int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logi
     ICRL_REQUIRE(logits && tokens_out && N > 0 && V > 0, "icrl_sample_tokens_lstm_cell: null pointer or empty shape");
     ICRL_REQUIRE(ld_logits >= V, "icrl_sample_tokens_lstm_cell: ld_logits < V");
     ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_sample_tokens_lstm_cell: vocabulary %d exceeds the 16384-entry LDS row", V);
-    ICRL_REQUIRE(mode == ICRL_SAMPLE || mode == ICRL_FORCED, "icrl_sample_tokens_lstm_cell: mode must be ICRL_SAMPLE or ICRL_FORCED");
-    ICRL_REQUIRE(mode != ICRL_SAMPLE || uniforms, "icrl_sample_tokens_lstm_cell: ICRL_SAMPLE needs uniforms");
+    const int base_mode = mode & ~ICRL_EMIT_DLOGITS;
+    ICRL_REQUIRE(base_mode == ICRL_SAMPLE || base_mode == ICRL_FORCED, "icrl_sample_tokens_lstm_cell: mode must be ICRL_SAMPLE or ICRL_FORCED");
+    ICRL_REQUIRE(base_mode != ICRL_SAMPLE || uniforms, "icrl_sample_tokens_lstm_cell: ICRL_SAMPLE needs uniforms");
+    ICRL_REQUIRE(!(mode & ICRL_EMIT_DLOGITS) || probs, "icrl_sample_tokens_lstm_cell: ICRL_EMIT_DLOGITS needs the probs output");
     ICRL_REQUIRE(pre && table && gates_out && c_prev && c_out && h_out, "icrl_sample_tokens_lstm_cell: null cell operand");
     ICRL_REQUIRE(ld_pre >= 2048 && ld_pre % 2 == 0 && reinterpret_cast<uintptr_t>(pre) % 8 == 0,
                  "icrl_sample_tokens_lstm_cell: pre must be 8-byte aligned with an even row stride >= 2048");

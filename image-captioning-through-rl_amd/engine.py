@@ -298,7 +298,7 @@ class A2CEngine:
             widths.append(e)
             ws.update(
                 Hbuf=f32(t_steps + 1, n, H), Cbuf=f32(t_steps + 1, n, H), gates=f32(t_steps, n, 4 * H),
-                X=f32(t_steps, n, e), logits=f32(n, v), probs=f32(s, n, v), logp=f32(s, n), entropy=f32(s, n),
+                X=f32(t_steps, n, e), logits=f32(n, v), logp=f32(s, n), entropy=f32(s, n),
                 dlogp=f32(s * n), dlogits=f32(s, n, v),
                 dHall=f32(t_steps, n, H), dgp=f32(t_steps, n, 4 * H), dc0=f32(n, H), dc1=f32(n, H), dh0=f32(n, H),
                 dX=f32(t_steps * n, e), Uvocab=f32(s * n, H), HsC=f32(s * n, H))
@@ -560,6 +560,7 @@ class A2CEngine:
         Hb[0].copy_(P["cnn2linear.bias"].expand_as(Hb[0]))
         hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True, dtype=self.pd)
         fused_step = self.E % 64 == 0 and self.pd == "f32"
+        mode_s = mode if mode == hip.GREEDY else mode | hip.EMIT_DLOGITS
         cell_done = False
         for k in range(t_steps):
             if not cell_done:
@@ -568,8 +569,10 @@ class A2CEngine:
             if k < p0 - 1:
                 continue
             st = k - (p0 - 1)
+            # the sampler leaves G0 = onehot(token) - softmax of its row (d log_prob / d logits, all the backward pass
+            # needs of the softmax) where a separate pass over the [rows, V] probabilities used to put it
             out = dict(uniforms=None if uniforms is None else uniforms[st * n:(st + 1) * n], log_prob=ws["logp"][st],
-                       probs=ws["probs"][st] if mode != hip.GREEDY else None,
+                       probs=ws["dlogits"][st] if mode != hip.GREEDY else None,
                        entropy=ws["entropy"][st] if (self.want_entropy and mode != hip.GREEDY) else None)
             if ev_table is not None and self.NEXT_CELL_FROM <= k + 1 < t_steps:
                 if ev_table is not True:
@@ -577,13 +580,13 @@ class A2CEngine:
                     ev_table = True
                 ext = ws["logits_ext"][:n]
                 hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3, dtype=self.pd)
-                hip.sample_tokens_lstm_cell(ext[:, :V], mode, tokT[k + 1], 1, ext[:, V:], ws["table_p"], gates[k + 1],
+                hip.sample_tokens_lstm_cell(ext[:, :V], mode_s, tokT[k + 1], 1, ext[:, V:], ws["table_p"], gates[k + 1],
                                             Cb[k + 1], Cb[k + 2], Hb[k + 2], **out)
                 cell_done = True
             else:
                 logits = ws["logits"][:n]
                 hip.gemm(Hb[k + 1], P["linear2vocab.weight"], logits, bias=P["linear2vocab.bias"], dtype=self.pd)
-                hip.sample_tokens(logits, mode, tokT[k + 1], 1, **out)
+                hip.sample_tokens(logits, mode_s, tokT[k + 1], 1, **out)
         # the embedding rows of the steps that took their input side from the table are gathered when the
         # backward pass asks for them
         ws["X_pending"] = ev_table is not None
@@ -977,13 +980,11 @@ class A2CEngine:
         coefficient dLoss/dlog_prob, G0 = onehot(token) - softmax, and their product with the vocabulary matrix
         U = G0 . W (what flows into the LSTM outputs is coef * U, row by row).  On `stream`, beside the chains."""
         P = self.P
-        tok_flat = ws["tokT"].view(-1)
         ev = torch.cuda.Event()
         ev.record(main)
         with torch.cuda.stream(stream):
             stream.wait_event(ev)
-            G0 = ws["dlogits"].view(s * n, self.vocab)
-            hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G0, tok_flat[p0 * n:], 1, None)
+            G0 = ws["dlogits"].view(s * n, self.vocab)   # left by the rollout's sampler launches
             hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ws["scratch_check"], b_kmajor=True, shared=True,
                           dtype=self.pd)
             done = torch.cuda.Event()
@@ -1291,8 +1292,6 @@ class A2CEngine:
         if ws.get("policy_early"):
             cur.wait_event(ws["ev_early"])
         else:
-            tok_flat = ws["tokT"].view(-1)
-            hip.policy_dlogits(ws["probs"].view(s * n, self.vocab), G0, tok_flat[p0 * n:], 1, None)
             hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ss, b_kmajor=True, shared=True, dtype=self.pd)
         dHall = ws["dHall"]
         if p0 > 1:

@@ -83,6 +83,7 @@ SIGNATURES = {
 }
 
 SAMPLE, GREEDY, FORCED = 0, 1, 2
+EMIT_DLOGITS = 16   # or-ed into SAMPLE / FORCED: the probs output receives onehot(token) - softmax
 ABI_VERSION = 2
 
 _lib = None

@@ -163,10 +163,14 @@ int icrl_policy_lstm_step(const float* emb, int wordvec_dim, const int64_t* toke
  *   mode ICRL_FORCED: token is read from tokens_out; only log_prob is produced.
  * tokens_out[i*token_stride] receives / holds the int64 token.  probs (optional,
  * [N,V]) receives the softmax; entropy (optional, [N]) the diagnostic
- * -sum p log p, which the reference's loss does NOT contain. */
+ * -sum p log p, which the reference's loss does NOT contain.
+ * mode | ICRL_EMIT_DLOGITS (with ICRL_SAMPLE or ICRL_FORCED): probs receives onehot(token) - softmax
+ * instead, i.e. d log_prob / d logits (autograd of trainers.py:458), what icrl_policy_dlogits would make of the
+ * softmax with coef = 1, bit for bit - written by the launch that has the row on chip anyway. */
 #define ICRL_SAMPLE 0
 #define ICRL_GREEDY 1
 #define ICRL_FORCED 2
+#define ICRL_EMIT_DLOGITS 16
 int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int mode,
                        const double* uniforms, int64_t* tokens_out, int64_t token_stride,
                        float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,

@@ -717,3 +717,28 @@ def test_policy_lstm_bptt_equals_the_launches_issued_one_by_one_and_autograd(n, 
     np.testing.assert_allclose(dc0.cpu().numpy(), c0.grad.numpy(), rtol=2e-4, atol=2e-6)
     dw = (dgp.view(-1, 4 * H).cpu().double().t() @ h_all[:t_steps].reshape(-1, H).cpu().double())
     np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("v,mode", [(10000, "sample"), (10000, "forced"), (257, "sample")])
+def test_sampler_emits_onehot_minus_softmax_bit_equal_to_the_separate_pass(v, mode):
+    """mode | EMIT_DLOGITS: the probs output holds what icrl_policy_dlogits makes of the softmax (coef = 1)."""
+    rs = np.random.RandomState(11)
+    n = 96
+    logits = dev(rnd(rs, n, v, scale=2.0))
+    u = dev(rs.random_sample(n), torch.float64)
+    m = hip.SAMPLE if mode == "sample" else hip.FORCED
+    tok = torch.zeros(n, dtype=torch.int64, device="cuda")
+    if mode == "forced":
+        tok.copy_(dev(rs.randint(0, v, size=n), torch.int64))
+    tok2 = tok.clone()
+    lp, lp2 = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    probs, g0 = torch.empty(n, v, device="cuda"), torch.empty(n, v, device="cuda")
+    hip.sample_tokens(logits, m, tok, 1, uniforms=u if mode == "sample" else None, log_prob=lp, probs=probs)
+    hip.sample_tokens(logits, m | hip.EMIT_DLOGITS, tok2, 1, uniforms=u if mode == "sample" else None, log_prob=lp2,
+                      probs=g0)
+    want = torch.empty(n, v, device="cuda")
+    hip.policy_dlogits(probs, want, tok, 1, None)
+    torch.cuda.synchronize()
+    assert torch.equal(tok, tok2) and torch.equal(lp, lp2) and torch.equal(g0, want)
+    with pytest.raises(RuntimeError, match="EMIT_DLOGITS"):
+        hip.sample_tokens(logits, hip.GREEDY | hip.EMIT_DLOGITS, tok2, 1, probs=g0)
