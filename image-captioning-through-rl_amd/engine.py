@@ -1173,27 +1173,45 @@ class A2CEngine:
         ev_loss = torch.cuda.Event()
         ev_loss.record(main)
 
-        # ---- value network: head, then the chain's BPTT (main stream)
-        self._value_head_backward(ws, features, n, s)
+        # ---- value network: what the chain's BPTT needs of the head's backward pass, then the BPTT (main stream);
+        # the head's own weight gradients are not on that path: they are queued on the third stream behind the
+        # vocabulary gradients (_policy_backward), where they run beside the end of the step
+        late = self.concurrent
+        self._value_head_backward(ws, features, n, s, weights=not late)
+        ws["head_grads_pending"] = (features, n, s) if late else None
         self._value_chain_backward(ws, n, p0, s, fc, main, side, plan, ev_loss, features)
+        ev_head = ws.pop("ev_head_grads", None)
+        if ev_head is not None:
+            main.wait_event(ev_head)
+        elif ws.pop("head_grads_pending", None) is not None:   # nobody picked them up: here and now
+            self._value_head_weight_grads(ws, features, n, s, ws["scratch_main"], ws["cs_main"])
 
-    def _value_head_backward(self, ws, features, n, s):
+    def _value_head_backward(self, ws, features, n, s, weights=True):
         """Backward of the two linear layers of the value head (models.py:175-178) from ws["dvalue"]:
-        their weight gradients and d_emit, the gradient entering the chain at each call's last column."""
-        V, gV = self.V, self.gV
+        d_emit, the gradient entering the chain at each call's last column, and (weights=True) their weight
+        gradients."""
+        V = self.V
         dvalue = ws["dvalue"].view(s * n, 1)
         dY = ws["dY"]
         hip.gemm(dvalue, V["linear2.weight"], dY, b_kmajor=True)                       # dY = dvalue (x) w2
-        sm = ws["scratch_main"]   # the two long-k weight gradients are split over k (partial slabs in scratch)
-        hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], sm, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
-        hip.colsum(dvalue, gV["linear2.bias"], scratch=ws["cs_main"])
-        w1, gw1 = V["linear1.weight"], gV["linear1.weight"]
-        hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], sm, a_kmajor=True, b_kmajor=True)
+        hip.gemm(dY, V["linear1.weight"][:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
+        if weights:
+            self._value_head_weight_grads(ws, features, n, s, ws["scratch_main"], ws["cs_main"])
+
+    def _value_head_weight_grads(self, ws, features, n, s, scratch, cs):
+        """Weight and bias gradients of the value head's two linear layers, from ws["dvalue"] and ws["dY"], on the
+        current stream; scratch / cs: split-K slabs and fixed-order column-sum partials of that stream."""
+        V, gV = self.V, self.gV
+        dvalue = ws["dvalue"].view(s * n, 1)
+        dY = ws["dY"]
+        hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], scratch, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
+        hip.colsum(dvalue, gV["linear2.bias"], scratch=cs)
+        gw1 = gV["linear1.weight"]
+        hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, a_kmajor=True, b_kmajor=True)
         gw1[:, self.F:].copy_(ws["gw1h"])
-        hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1), scratch=ws["cs_main"])
+        hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1), scratch=cs)
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
-        hip.colsum(dY, gV["linear1.bias"], scratch=ws["cs_main"])
-        hip.gemm(dY, w1[:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
+        hip.colsum(dY, gV["linear1.bias"], scratch=cs)
 
     def _value_chain_backward(self, ws, n, p0, s, fc, main, side, plan, ev_loss, features=None):
         """The value chain's BPTT and everything that consumes it.  With ev_loss the side stream also
@@ -1310,6 +1328,11 @@ class A2CEngine:
             hip.colsum(G0, gP["linear2vocab.bias"], scratch=cs, row_scale=coef)
             ev_vocab = torch.cuda.Event()
             ev_vocab.record(other)
+            pending = ws.pop("head_grads_pending", None) if other is not cur else None
+            if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
+                self._value_head_weight_grads(ws, *pending, sc, cs)
+                ws["ev_head_grads"] = torch.cuda.Event()
+                ws["ev_head_grads"].record(other)
             if other is not cur:
                 self._mark("check:vocab_grads_done")
         dgp = ws["dgp"]
