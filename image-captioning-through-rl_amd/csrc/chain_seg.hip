@@ -349,6 +349,42 @@ __global__ __launch_bounds__(256) void seam_check_fwd(const float* __restrict__ 
     }
 }
 
+// Both forward chains' seam checks and the abort poison in ONE launch (three tiny launches in a row sit on the
+// step's critical path): blocks [0, nb) check the LSTM chain's seams, blocks [nb, 2 nb) the GRU chain's; a launch
+// that gave up waiting (abort word set) reports +inf for both.
+__global__ __launch_bounds__(256) void seam_check_fwd_pair(const float* __restrict__ a_v, const float* __restrict__ b_v,
+                                                           Geom gv, float* __restrict__ err_v,
+                                                           const float* __restrict__ a_r, const float* __restrict__ b_r,
+                                                           Geom gr, float* __restrict__ err_r,
+                                                           const unsigned* __restrict__ abort_w, int nb) {
+    __shared__ float red[4];
+    const bool second = (int)blockIdx.x >= nb;
+    const float* seam_a = second ? a_r : a_v;
+    const float* seam_b = second ? b_r : b_v;
+    const Geom& g = second ? gr : gv;
+    const int width = second ? H : 2 * H;
+    float* err = second ? err_r : err_v;
+    const int b0 = second ? blockIdx.x - nb : blockIdx.x;
+    float d = 0.f;
+    for (int e = b0 * 256 + threadIdx.x; e < g.K * width; e += nb * 256) {
+        const int j = e / width;
+        if (j >= 1 && (int64_t)j * g.Ls < g.total && (int64_t)j * g.Ls - g.W > 0) {
+            const float a = seam_a[e], b = seam_b[e];
+            float v = fabsf(a - b) / fmaxf(1.f, fabsf(b));
+            if (!(v == v)) v = INFINITY;
+            d = fmaxf(d, v);
+        }
+    }
+    d = wave_max(d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (*abort_w != 0) d = INFINITY;
+        if (d > 0.f) atomic_max_nonneg(err, d);
+    }
+}
+
 // ------------------------------------------------------------------ LSTM backward step
 // State entering position p (walking down): dh = W_hh^T dgates(p+1) and dc (carried).
 // Step mp handles step Ls + W - 1 - mp of every segment.  final = 1: only the product, written
@@ -623,9 +659,11 @@ __global__ __launch_bounds__(256) void seg_gru_bwd_step(const float* __restrict_
 
 // seam j (between segments j and j+1): warm-up state of segment j vs final state of j+1;
 // err_abs = max |a - b|, ref_abs = max |b| over dh and dc of all seams.
+// abort_w (may be null): the abort word of a persistent launch; a launch that gave up waiting reports +inf.
 __global__ __launch_bounds__(256) void seam_check_bwd(const float* __restrict__ seam_a, const float* __restrict__ dh_fin,
                                                       const float* __restrict__ dc, Geom g,
-                                                      float* __restrict__ err_abs, float* __restrict__ ref_abs) {
+                                                      float* __restrict__ err_abs, float* __restrict__ ref_abs,
+                                                      const unsigned* __restrict__ abort_w = nullptr) {
     __shared__ float red[8];
     float d = 0.f, r = 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < g.K * 2 * H; e += gridDim.x * 256) {
@@ -645,6 +683,7 @@ __global__ __launch_bounds__(256) void seam_check_bwd(const float* __restrict__ 
     if (threadIdx.x == 0) {
         d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         r = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        if (abort_w != nullptr && *abort_w != 0) { d = INFINITY; r = fmaxf(r, 1.f); }
         if (d > 0.f) atomic_max_nonneg(err_abs, d);
         if (r > 0.f) atomic_max_nonneg(ref_abs, r);
     }
@@ -1650,15 +1689,23 @@ __global__ __launch_bounds__(256, 1) void seg_warm_bwd(WarmBwdArgs a, unsigned* 
 #undef WB_LOAD
 }
 
-__global__ void poison_on_abort1(const unsigned* abort_w, float* seam) {
-    if (*abort_w != 0) { seam[0] = INFINITY; seam[1] = 1.f; }
-}
-
 // after the seam checks: a launch that gave up waiting must not pass them
 __global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* seam_r) {
     if (*abort_w != 0) { *seam_v = INFINITY; *seam_r = INFINITY; }
 }
 int seam_blocks(int64_t elems) { return (int)std::min<int64_t>(128, (elems + 255) / 256); }
+
+// Up to five regions cleared by ONE launch (a persistent chain launch is preceded by that many small clears -
+// polled words, exchanged state, seam errors - and each hipMemsetAsync is a launch of its own on the step's
+// critical path).  Counts in floats; a null pointer or a zero count skips the region.
+struct ZeroArgs { float* p[5]; int64_t n[5]; };
+__global__ __launch_bounds__(256) void zero_regions(ZeroArgs z) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        if (z.p[r] == nullptr) continue;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < z.n[r]; i += (int64_t)gridDim.x * 256) z.p[r][i] = 0.f;
+    }
+}
 
 // a launch that gave up waiting, reported through a status word (the per-row chains have no seam error)
 __global__ void flag_on_abort(const unsigned* abort_w, int* status) {
@@ -1723,7 +1770,8 @@ int bwd_steps(const Geom& g, const float* w_hh, const float* saved, const float*
 // phase: 0 = everything, 1 = up to and including the cheap warm-up launch, 2 = the float32 launch alone (after a
 // phase-1 call on the same workspaces).
 int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipStream_t st, unsigned** abort_out,
-                 int cheap_v = 0, int cheap_r = 0, int phase = 0) {
+                 int cheap_v = 0, int cheap_r = 0, int phase = 0, float* err_a = nullptr, float* err_b = nullptr,
+                 int err_floats = 0) {
     const int K = v.g.K;
     const int64_t kh = (int64_t)K * H;
     const int ny = (K + 31) / 32;
@@ -1731,10 +1779,10 @@ int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipSt
     unsigned* words = reinterpret_cast<unsigned*>(work_v + 12 * kh);
     const size_t word_bytes = ((size_t)(2 * ny * 16 + 4 + 2 * ny * 32) * sizeof(unsigned) + 255) / 256 * 256;
     ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
-    if (phase != 2) {
-        ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
-        ICRL_HIP(hipMemsetAsync(work_v, 0, sizeof(float) * 2 * kh, st));
-        ICRL_HIP(hipMemsetAsync(work_r, 0, sizeof(float) * 2 * kh, st));
+    if (phase != 2) {   // polled words, both chains' exchanged state and (err_a, err_b: the caller's error words)
+        ZeroArgs z{{reinterpret_cast<float*>(words), work_v, work_r, err_a, err_b},
+                   {(int64_t)(word_bytes / sizeof(float)), 2 * kh, 2 * kh, err_floats, err_floats}};
+        hipLaunchKernelGGL(zero_regions, dim3(128), dim3(256), 0, st, z);
     }
     v.hb = work_v; v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
     r.hb = work_r; r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 16;
@@ -1781,7 +1829,7 @@ int solo_persist(ChainArgs& a, int gates, float* work, hipStream_t st, unsigned*
 }
 
 // cheap: the first steps of the warm-up that run on seg_warm_bwd (16-bit split products) before the float32 launch
-int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, int cheap = 0) {
+int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, int cheap = 0, float* seam_err = nullptr) {
     const int K = a.g.K;
     const int64_t kh = (int64_t)K * H;
     const int ny = (K + 31) / 32;
@@ -1790,7 +1838,11 @@ int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, i
     // then the abort word, then the flags of the 16-bit launch
     const size_t word_bytes = ((size_t)(2 * ny * 32 + 4) * sizeof(unsigned) + 255) / 256 * 256;
     ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
-    ICRL_HIP(hipMemsetAsync(words, 0, word_bytes, st));
+    {
+        ZeroArgs z{{reinterpret_cast<float*>(words), seam_err, nullptr, nullptr, nullptr},
+                   {(int64_t)(word_bytes / sizeof(float)), seam_err ? 2 : 0, 0, 0, 0}};
+        hipLaunchKernelGGL(zero_regions, dim3(8), dim3(256), 0, st, z);
+    }
     a.dgx = work; a.dc = work + 8 * kh; a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
     *abort_out = words + ny * 32;
     if (cheap > 0) {
@@ -1970,23 +2022,17 @@ int pair_fwd_impl(const char* who, const float* xproj_v, const float* w_hh_v, co
     ICRL_REQUIRE(phase >= 0 && phase <= 2 && (phase == 0 || cheap_v > 0 || cheap_r > 0),
                  "%s: phase must be 0, or 1 / 2 with a 16-bit part to run", who);
     hipStream_t st = icrl::as_stream(stream);
-    if (phase != 2) {
-        ICRL_HIP(hipMemsetAsync(seam_err_v, 0, sizeof(float), st));
-        ICRL_HIP(hipMemsetAsync(seam_err_r, 0, sizeof(float), st));
-    }
     v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v; v.state_in = nullptr;
     r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = saved_r; r.h_emit = h_emit_r; r.state_in = nullptr;
     unsigned* abort_w = nullptr;
-    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w, cheap_v, cheap_r, phase)) return rc;
+    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w, cheap_v, cheap_r, phase, seam_err_v, seam_err_r, 1)) return rc;
     if (phase == 1) {
         ICRL_LAUNCH_CHECK();
         return ICRL_OK;
     }
-    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(v.g.K * 2 * H)), dim3(256), 0, st, v.seam_a, v.seam_b, v.g,
-                       2 * H, seam_err_v);
-    hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(r.g.K * H)), dim3(256), 0, st, r.seam_a, r.seam_b, r.g, H,
-                       seam_err_r);
-    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err_v, seam_err_r);
+    const int nb = seam_blocks(v.g.K * 2 * H);
+    hipLaunchKernelGGL(seam_check_fwd_pair, dim3(2 * nb), dim3(256), 0, st, v.seam_a, v.seam_b, v.g, seam_err_v, r.seam_a,
+                       r.seam_b, r.g, seam_err_r, abort_w, nb);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -2095,13 +2141,11 @@ int lstm_bwd_persist_impl(const char* who, const float* w_hh, const float* saved
                  "%s: the 16-bit warm-up launch needs a multiple of 32 segments that fits the device (%d given)", who,
                  segments);
     hipStream_t st = icrl::as_stream(stream);
-    ICRL_HIP(hipMemsetAsync(seam_err, 0, 2 * sizeof(float), st));
     a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgv = dgates;
     unsigned* abort_w = nullptr;
-    if (int rc = bwd_persist(a, work, st, &abort_w, cheap)) return rc;
+    if (int rc = bwd_persist(a, work, st, &abort_w, cheap, seam_err)) return rc;
     hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
-                       a.g, seam_err, seam_err + 1);
-    hipLaunchKernelGGL(poison_on_abort1, dim3(1), dim3(1), 0, st, abort_w, seam_err);
+                       a.g, seam_err, seam_err + 1, (const unsigned*)abort_w);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

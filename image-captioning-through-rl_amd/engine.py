@@ -1065,6 +1065,11 @@ class A2CEngine:
             if pair:
                 ev_xpr = torch.cuda.Event()
                 ev_xpr.record(side)
+                if backward:
+                    # the value network's embedding rows, which only its input-side weight gradient reads: gathered
+                    # here beside the chains instead of at the end of the step (this stream's later events cover it)
+                    hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
+                    ws["Xv_gathered"] = True
             elif seg_r:
                 hip.gru_chain_fwd_seg(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                       plan_r[1], plan_r[2], ws["hr"], ws["work_r"], ws["seam"][2:4], full_calls=fc,
@@ -1274,7 +1279,8 @@ class A2CEngine:
         else:
             dgsum = ws["dGsum"]
             hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
-        if ev_loss is not None:   # the A2C step took its input projections from the per-word table: gather x now
+        if ev_loss is not None and not ws.pop("Xv_gathered", False):
+            # the A2C step took its input projections from the per-word table: gather x now
             hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
         hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], sm, a_kmajor=True, b_kmajor=True)
         hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_main"])
