@@ -1047,6 +1047,7 @@ class A2CEngine:
         collapsed = fc < s
         self._chain_capacity(ws, tv, tr if collapsed else 0)
         tok_flat = ws["tokT"].view(-1)
+        ws["Xv_gathered"] = False     # set below when this attempt gathers the value network's embedding rows early
         seg, seg_r, rows = plan[0] == "segmented", plan_r[0] == "segmented", plan[0] == "rows"
         keep = backward or collapsed      # the value chain's activations: for the BPTT, and for the replay check
 
