@@ -1,4 +1,4 @@
-// Batched autoregressive sampler: one 256-thread workgroup per row of logits[N,V].
+// Batched autoregressive sampler: one workgroup (256 threads, 512 for large vocabularies) per row of logits[N,V].
 //
 // Sampling reproduces numpy.random.choice(V, p=softmax(logits)) for an externally
 // supplied uniform u: the probabilities are float32 (the reference copies a float32
@@ -14,22 +14,32 @@ using namespace icrl;
 
 constexpr int H = kHidden;
 
+// Reductions over a workgroup of NW waves (red: NW floats of LDS)
+template <int NW>
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+    return m;
 }
 
+// fixed order: pairs of neighbouring waves first, then the pair sums in ascending order
+template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float s = red[0] + red[1];
+#pragma unroll
+    for (int w = 2; w < NW; w += 2) s += red[w] + red[w + 1];
+    return s;
 }
 
 // The policy LSTM's next cell update, run by the workgroup that has just fixed its row's token (pre == nullptr:
@@ -48,17 +58,18 @@ struct NextCell {
 // DL: the `probs` output receives onehot(token) - softmax instead of the softmax (what the policy's backward pass
 // needs, up to the per-row coefficient dLoss / dlog_prob): -p from every thread in pass 3, and the thread that
 // wrote the token's entry corrects it to 1 - p once the token is fixed (same thread, same address: ordered).
-template <int MODE, bool DL>
-__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ logits, int64_t ld, int V,
+template <int MODE, bool DL, int NT>
+__global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ logits, int64_t ld, int V,
                                                      const double* __restrict__ uniforms,
                                                      int64_t* __restrict__ tokens, int64_t token_stride,
                                                      float* __restrict__ log_prob, int64_t lp_stride,
                                                      float* __restrict__ probs, float* __restrict__ entropy,
                                                      NextCell cell) {
     extern __shared__ __attribute__((aligned(16))) float row[];  // V floats
-    __shared__ float redf[4];
-    __shared__ double redd[4];
-    __shared__ int redi[4];
+    constexpr int NW = NT / 64;   // waves
+    __shared__ float redf[NW];
+    __shared__ double redd[NW];
+    __shared__ int redi[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = blockIdx.x;
     const float* src = logits + (int64_t)r * ld;
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         // argmax, first index wins on ties (torch.argmax on a CPU/GPU tensor row)
         float best = -INFINITY;
         int bi = 0x7fffffff;
-        for (int k = tid; k < V; k += 256) {
+        for (int k = tid; k < V; k += NT) {
             const float v = src[k];
             if (v > best) { best = v; bi = k; }
         }
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NW; ++w)
                 if (redf[w] > best || (redf[w] == best && redi[w] < bi)) { best = redf[w]; bi = redi[w]; }
             tokens[r * token_stride] = (int64_t)bi;
             if (log_prob) log_prob[r * lp_stride] = 0.f;
@@ -96,43 +107,43 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const int v4 = V / 4;
         const float4* src4 = reinterpret_cast<const float4*>(src);
         float4* row4 = reinterpret_cast<float4*>(row);
-        for (int k0 = 0; k0 < v4; k0 += 256 * 4) {
+        for (int k0 = 0; k0 < v4; k0 += NT * 4) {
             float4 t[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + tid + 256 * j;
+                const int k = k0 + tid + NT * j;
                 t[j] = (k < v4) ? src4[k] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + tid + 256 * j;
+                const int k = k0 + tid + NT * j;
                 if (k < v4) row4[k] = t[j];
                 m = fmaxf(fmaxf(m, fmaxf(t[j].x, t[j].y)), fmaxf(t[j].z, t[j].w));
             }
         }
     } else {
-        for (int k = tid; k < V; k += 256) {
+        for (int k = tid; k < V; k += NT) {
             const float v = src[k];
             row[k] = v;
             m = fmaxf(m, v);
         }
     }
-    m = block_max(m, redf);
-    // pass 2: exponentials, their float32 sum (element order of the sum: strided by 256, as below)
+    m = block_max<NW>(m, redf);
+    // pass 2: exponentials, their float32 sum (element order of the sum: strided by the workgroup size, as below)
     float s = 0.f;
-    for (int k = tid; k < V; k += 256) {
+    for (int k = tid; k < V; k += NT) {
         const float e = expf(row[k] - m);
         row[k] = e;
         s += e;
     }
-    s = block_sum(s, redf);
+    s = block_sum<NW>(s, redf);
     // pass 3: probabilities (float32 division, as torch's softmax does), optional outputs
     float ent = 0.f;
     if (vec) {
         const int v4 = V / 4;
         float4* row4 = reinterpret_cast<float4*>(row);
         float4* out4 = probs ? reinterpret_cast<float4*>(probs + (int64_t)r * V) : nullptr;
-        for (int k = tid; k < v4; k += 256) {
+        for (int k = tid; k < v4; k += NT) {
             float4 p = row4[k];
             p.x /= s; p.y /= s; p.z /= s; p.w /= s;
             row4[k] = p;
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
             }
         }
     } else {
-        for (int k = tid; k < V; k += 256) {
+        for (int k = tid; k < V; k += NT) {
             const float p = row[k] / s;
             row[k] = p;
             if (probs) probs[(int64_t)r * V + k] = DL ? 0.f - p : p;
@@ -153,18 +164,18 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         }
     }
     if (entropy) {
-        ent = block_sum(ent, redf);
+        ent = block_sum<NW>(ent, redf);
         if (tid == 0) entropy[r] = ent;
     }
     __syncthreads();
 
     int token;
     if (MODE == ICRL_SAMPLE) {
-        const int chunk = (V + 255) / 256;
+        const int chunk = (V + NT - 1) / NT;
         const int k0 = tid * chunk, k1 = min(k0 + chunk, V);
         double local = 0.;
         for (int k = k0; k < k1; ++k) local += (double)row[k];
-        // inclusive scan over the 256 chunk sums
+        // inclusive scan over the NT chunk sums
         double inc = local;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         if (lane == 63) redd[wave] = inc;
         __syncthreads();
         double wave_off = 0., total = 0.;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             if (w < wave) wave_off += redd[w];
             total += redd[w];
         }
@@ -195,7 +206,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         if (lane == 0) redi[wave] = cnt;
         __syncthreads();
-        token = redi[0] + redi[1] + redi[2] + redi[3];
+        token = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) token += redi[w];
         if (token > V - 1) token = V - 1;
         if (tid == 0) tokens[r * token_stride] = (int64_t)token;
     } else {
@@ -205,14 +218,14 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ l
         const bool ok = token >= 0 && token < V;
         log_prob[r * lp_stride] = ok ? logf(row[token]) : NAN;
     }
-    if (DL && probs && token >= 0 && token < V && tid == (vec ? (token >> 2) & 255 : token & 255))
+    if (DL && probs && token >= 0 && token < V && tid == (vec ? (token >> 2) & (NT - 1) : token & (NT - 1)))
         probs[(int64_t)r * V + token] = 1.f - row[token];
     if (cell.pre != nullptr && token >= 0 && token < V) {
         // gates = h . W_hh^T + (W_ih x + b) for the token just fixed, then the cell (models.py:80): two units a lane
         const float* pr = cell.pre + (int64_t)r * cell.ld_pre;
         const float* tb = cell.table + (int64_t)token * (4 * H);
         float* go_ = cell.gates_out + (int64_t)r * (4 * H);
-        for (int u = 2 * tid; u < H; u += 512) {
+        for (int u = 2 * tid; u < H; u += 2 * NT) {
             float2 g4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -284,27 +297,35 @@ int launch_sampler(const float* logits, int64_t ld_logits, int N, int V, int mod
                    float* entropy, const NextCell& cell, icrl_stream_t stream) {
     hipStream_t st = icrl::as_stream(stream);
     const size_t lds = (size_t)V * sizeof(float);
-    dim3 grid(N), block(256);
+    // 512 threads a row from 4096 words on: the row's passes are chains of dependent reductions, and a CU holds
+    // only as many rows as fit its LDS; twice the waves per row halve every thread's share of them (the A2C
+    // step's rollout 2.28 -> 2.17 ms; 1024 threads gain nothing more).  Smaller vocabularies keep 256 threads -
+    // and with them the summation order, so their results do not change.
+    const bool wide = V >= 4096;
+    dim3 grid(N), block(wide ? 512 : 256);
     const bool dl = (mode & ICRL_EMIT_DLOGITS) != 0;
     mode &= ~ICRL_EMIT_DLOGITS;
-#define ICRL_SAMPLER_LAUNCH(M, D, LDS)                                                                              \
-    hipLaunchKernelGGL((sample_kernel<M, D>), grid, block, LDS, st, logits, ld_logits, V, uniforms, tokens_out,     \
+#define ICRL_SAMPLER_LAUNCH2(M, D, T, LDS)                                                                          \
+    hipLaunchKernelGGL((sample_kernel<M, D, T>), grid, block, LDS, st, logits, ld_logits, V, uniforms, tokens_out,  \
                        token_stride, log_prob, log_prob_stride, probs, entropy, cell)
+#define ICRL_SAMPLER_LAUNCH(M, D, LDS)                                                                              \
+    if (wide) ICRL_SAMPLER_LAUNCH2(M, D, 512, LDS); else ICRL_SAMPLER_LAUNCH2(M, D, 256, LDS)
     switch (mode) {
         case ICRL_SAMPLE:
-            if (dl) ICRL_SAMPLER_LAUNCH(ICRL_SAMPLE, true, lds); else ICRL_SAMPLER_LAUNCH(ICRL_SAMPLE, false, lds);
+            if (dl) { ICRL_SAMPLER_LAUNCH(ICRL_SAMPLE, true, lds); } else { ICRL_SAMPLER_LAUNCH(ICRL_SAMPLE, false, lds); }
             break;
         case ICRL_GREEDY:
             if (dl) { icrl::set_error("icrl_sample_tokens: ICRL_EMIT_DLOGITS needs ICRL_SAMPLE or ICRL_FORCED"); return ICRL_ERR_ARG; }
             ICRL_SAMPLER_LAUNCH(ICRL_GREEDY, false, 0);
             break;
         case ICRL_FORCED:
-            if (dl) ICRL_SAMPLER_LAUNCH(ICRL_FORCED, true, lds); else ICRL_SAMPLER_LAUNCH(ICRL_FORCED, false, lds);
+            if (dl) { ICRL_SAMPLER_LAUNCH(ICRL_FORCED, true, lds); } else { ICRL_SAMPLER_LAUNCH(ICRL_FORCED, false, lds); }
             break;
         default:
             icrl::set_error("icrl_sample_tokens: unknown mode %d", mode);
             return ICRL_ERR_ARG;
     }
+#undef ICRL_SAMPLER_LAUNCH2
 #undef ICRL_SAMPLER_LAUNCH
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
