@@ -1,0 +1,20 @@
+"""One f32 GEMM shape, a few launches, for counter collection:  python tools/gemm_one.py M N K kA kB tile [launches]"""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+hip = importlib.import_module(bench.PKG + ".hipabi")
+m, n, k, ka, kb, tile = (int(x) for x in sys.argv[1:7])
+reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+dev = torch.device("cuda", 0)
+a = torch.randn((k, m) if ka else (m, k), device=dev)
+b = torch.randn((k, n) if kb else (n, k), device=dev)
+out = torch.empty(m, n, device=dev)
+for _ in range(reps):
+    hip.gemm(a, b, out, a_kmajor=bool(ka), b_kmajor=bool(kb), tile=tile)
+torch.cuda.synchronize()
