@@ -1,0 +1,318 @@
+// f32 GEMM at close to f32 accuracy on the bf16 matrix instruction: every operand element is cut into three
+// bf16 pieces x = hi + mid + lo (exactly: 3 x 8 significant bits) on its way into LDS, and a product of two
+// elements is the six piece products of weight 2^-16 and above,
+//     a.b ~ hi.hi + (hi.mid + mid.hi) + (mid.mid + hi.lo + lo.hi),
+// summed in f32 by v_mfma_f32_32x32x16_bf16 (every piece product is exact; what is dropped, mid.lo + lo.mid +
+// lo.lo, is below 2^-23 of |a.b|, the size of one f32 rounding of the product).  Six bf16 instructions do the work
+// of sixteen v_mfma_f32_32x32x2_f32, so a long product runs at about twice the exact-f32 kernel's rate; sums
+// are accumulated in a different order and with different roundings than there, so results agree to f32 rounding
+// error, not bit for bit.  Used for the two vocabulary-sized gradient products of the policy network.
+//
+// Same calling convention, operand layouts, split-K slabs and XCD-aware tile order as gemm_f32.hip; 128x128
+// tiles, k stages of 32, LDS images as in gemm_bf16.hip (three of them per operand), two workgroups per CU.
+#include "icrl_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 8;   // bf16 elements per LDS row (20 dwords: the ds_read_b128 of 16 rows at one k offset is conflict-free)
+constexpr int BM = 128, BN = 128;
+constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;      // one piece's image of an operand tile (bf16 elements)
+constexpr int BUF = 3 * (A_PLANE + B_PLANE);               // one stage: A hi, mid, lo, B hi, mid, lo (60 KB)
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 p;
+    p[0] = (__bf16)lo;
+    p[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// x = hi + mid + lo exactly, each piece a bf16 (8 significant bits each: x - hi and (x - hi) - mid are exact in f32
+// and the last remainder has at most 8 bits); two elements at a time, packed {low half: first element}.
+__device__ __forceinline__ void split3(float x, float y, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pack2(x, y);
+    const float rx = x - __builtin_bit_cast(float, hi << 16), ry = y - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = pack2(rx, ry);
+    const float sx = rx - __builtin_bit_cast(float, mid << 16), sy = ry - __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = pack2(sx, sy);
+}
+
+// Staging of one operand tile of ROWS x BK: global -> registers (load), registers -> three LDS images [row][k]
+// `plane` elements apart (store3).
+// KM = false (k contiguous in memory, [rows][ld]): piece i of thread tid is row f / 8, k quad f % 8, f = tid + 256 i:
+// one float4, stored as three 8-byte pieces.
+// KM = true (rows contiguous in memory, [K][ld]): piece i is row f % ROWS, k octet f / ROWS: eight dword loads, each
+// of them 64 consecutive rows per wave, stored as three 16-byte pieces (eight lanes of a store hit eight different
+// bank groups; a thread that owned four rows of one k, as float4 loads along the rows would have it, puts the
+// lanes of a store four rows apart, which with rows a multiple of 16 bytes apart is two banks for all of them).
+template <int ROWS, bool KM>
+struct Stage {
+    static constexpr int PIECES = KM ? ROWS * BK / 8 / 256 : ROWS * BK / 4 / 256;
+    float x[PIECES][KM ? 8 : 4];
+
+    // EDGE = false: the tile lies inside the matrix and (KM = false) every float4 is aligned: plain loads, no branches.
+    template <bool EDGE>
+    __device__ __forceinline__ void load(const float* base, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + 256 * i;
+            if (!KM) {
+                const int gr = row0 + f / 8, gk = k0 + 4 * (f % 8);
+                const float* p = base + (int64_t)gr * ld + gk;
+                if (!EDGE) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[i][e] = (gr < nrows && gk + e < kend) ? p[e] : 0.f;
+                }
+            } else {
+                const int gr = row0 + f % ROWS, gk = k0 + 8 * (f / ROWS);
+                const float* p = base + (int64_t)gk * ld + gr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[i][e] = (!EDGE || (gr < nrows && gk + e < kend)) ? p[e * ld] : 0.f;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store3(__bf16* lds, int plane, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + 256 * i;
+            if (!KM) {
+                uint2 w[3];
+                split3(x[i][0], x[i][1], w[0].x, w[1].x, w[2].x);
+                split3(x[i][2], x[i][3], w[0].y, w[1].y, w[2].y);
+                __bf16* dst = lds + (f / 8) * LDK + 4 * (f % 8);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = w[p];
+            } else {
+                u32x4 w[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hi, mid, lo;
+                    split3(x[i][2 * e], x[i][2 * e + 1], hi, mid, lo);
+                    w[0][e] = hi; w[1][e] = mid; w[2][e] = lo;
+                }
+                __bf16* dst = lds + (f % ROWS) * LDK + 8 * (f / ROWS);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * plane) = w[p];
+            }
+        }
+    }
+};
+
+// Fragment of lane (r = lane & 31, h = lane >> 5) for k-step s of 16: elements k = 16 s + 8 h + j, j = 0..7 of row r
+__device__ __forceinline__ bf16x8 frag(const __bf16* lds, int row, int kstep, int h) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + row * LDK + 8 * (2 * kstep + h)));
+}
+
+struct GemmArgs {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int M, N, K;
+    const float* bias;
+    int accumulate;
+    int kchunk;        // k-range per split (split-K); a multiple of BK
+    int64_t slab;      // C offset (floats) between split-K partial results
+};
+
+template <bool A_KM, bool B_KM, bool EDGE>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], __bf16* lds, int m0, int n0, int kbeg,
+                                       int kend, int nk, int tid) {
+    constexpr int DEPTH = 2;   // stages in flight in registers
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    Stage<BM, A_KM> sa[DEPTH];
+    Stage<BN, B_KM> sb[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) {
+            sa[d].template load<EDGE>(g.A, g.lda, m0, g.M, kbeg + d * BK, kend, tid);
+            sb[d].template load<EDGE>(g.B, g.ldb, n0, g.N, kbeg + d * BK, kend, tid);
+        }
+    // One LDS image of a stage (60 KB) so that two workgroups share a CU: while one multiplies, the other cuts its
+    // next stage into pieces and writes it (two barriers per stage: after the last reads of the stage before,
+    // after the writes of this one).
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kt = kt0 + d;
+            if (kt < nk) {
+                const __bf16* la = lds;
+                const __bf16* lb = la + 3 * A_PLANE;
+                if (kt > 0) __syncthreads();
+                sa[d].store3(lds, A_PLANE, tid);
+                sb[d].store3(lds + 3 * A_PLANE, B_PLANE, tid);
+                if (kt + DEPTH < nk) {
+                    sa[d].template load<EDGE>(g.A, g.lda, m0, g.M, kbeg + (kt + DEPTH) * BK, kend, tid);
+                    sb[d].template load<EDGE>(g.B, g.ldb, n0, g.N, kbeg + (kt + DEPTH) * BK, kend, tid);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            av[i][p] = frag(la + p * A_PLANE, wr * 64 + i * 32 + l31, ks, h);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            bv[j][p] = frag(lb + p * B_PLANE, wc * 64 + j * 32 + l31, ks, h);
+                    // piece products, smallest first: (a piece, b piece) with piece 0 = hi, 1 = mid, 2 = lo
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA[q]], bv[j][PB[q]], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // XCD-aware tile order (as in gemm_f32.hip): workgroup b runs on XCD b % 8; every XCD gets one contiguous run of
+    // (split, tile); tiles are walked in bands of 8 along the dimension of the larger operand, in 8 x 8 blocks.
+    constexpr int BAND = 8;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int split = bid / tiles;
+    const int id = bid - split * tiles;
+    int mt, nt;
+    {
+        const bool m_fast = g.M < g.N;
+        const int tf = m_fast ? tiles_m : tiles_n, ts = m_fast ? tiles_n : tiles_m;
+        const int b = id / (tf * BAND), r = id - b * tf * BAND;
+        const int w = min(BAND, ts - b * BAND);
+        const int c = r / (BAND * w), r2 = r - c * BAND * w;
+        const int hc = min(BAND, tf - c * BAND);
+        const int s_in = r2 / hc, f_in = r2 - s_in * hc;
+        const int f = c * BAND + f_in, sl = b * BAND + s_in;
+        mt = m_fast ? f : sl;
+        nt = m_fast ? sl : f;
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    float* const Cout = g.C + (int64_t)split * g.slab;
+
+    const bool aligned = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(g.B) % 16 == 0) &&
+                         g.lda % 4 == 0 && g.ldb % 4 == 0 && kbeg % 4 == 0;
+    const bool interior = aligned && m0 + BM <= g.M && n0 + BN <= g.N;
+    const int full = (kend - kbeg) / BK;
+    if (interior && full > 0) {
+        k_loop<A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
+        if (full < nk) {
+            __syncthreads();
+            k_loop<A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
+        }
+    } else if (nk > 0) {
+        k_loop<A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
+    }
+
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float badd = (g.bias && split == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M) {
+                    float* dst = Cout + (int64_t)row * g.ldc + col;
+                    float v = acc[i][j][r] + badd;
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <bool A_KM, bool B_KM>
+int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_f32x3_kernel<A_KM, B_KM>), grid, dim3(256), 0, st, g);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
+             int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int splits, int64_t slab,
+             hipStream_t st, const char* who) {
+    ICRL_REQUIRE(A && B && C, "%s: null operand", who);
+    ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty shape %dx%dx%d", who, M, N, K);
+    ICRL_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N,
+                 "%s: leading dimension smaller than the row length", who);
+    ICRL_REQUIRE(splits >= 1 && splits <= 64, "%s: splits must be in [1, 64]", who);
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.accumulate = accumulate;
+    const int ksteps = (K + BK - 1) / BK;
+    g.kchunk = ((ksteps + splits - 1) / splits) * BK;
+    g.slab = slab;
+    const dim3 grid(((M + BM - 1) / BM) * ((N + BN - 1) / BN) * splits);
+    if (!a_kmajor && !b_kmajor) return launch_one<false, false>(g, grid, st);
+    if (!a_kmajor && b_kmajor) return launch_one<false, true>(g, grid, st);
+    if (a_kmajor && !b_kmajor) return launch_one<true, false>(g, grid, st);
+    return launch_one<true, true>(g, grid, st);
+}
+
+}  // namespace
+
+extern "C" int icrl_gemm_f32x3(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
+                               const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
+                               int M, int N, int K, const float* bias, const float* bias2,
+                               int accumulate, int tile, icrl_stream_t stream) {
+    ICRL_REQUIRE(!a_rows && !bias2, "icrl_gemm_f32x3: no row gather and no second bias in this kernel");
+    ICRL_REQUIRE(tile == 0 || tile == 1, "icrl_gemm_f32x3: tile must be 0 or 1 (128x128)");
+    return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias, accumulate, 1, 0,
+                    icrl::as_stream(stream), "icrl_gemm_f32x3");
+}
+
+extern "C" int icrl_gemm_f32x3_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
+                                      int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M, int N,
+                                      int K, int splits, int tile, icrl_stream_t stream) {
+    ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f32x3_splitk: slabs overlap");
+    ICRL_REQUIRE(tile == 0 || tile == 1, "icrl_gemm_f32x3_splitk: tile must be 0 or 1 (128x128)");
+    return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, 0, splits, slab_stride,
+                    icrl::as_stream(stream), "icrl_gemm_f32x3_splitk");
+}

@@ -182,7 +182,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
-                 frozen_reward=False, warm16=True, warm16_backward=False,
+                 frozen_reward=False, warm16=True, warm16_backward=False, vocab_grad_products="f32x3",
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -204,6 +204,10 @@ class A2CEngine:
         # float32 sums.  The chains, heads, softmax / sampler and every reduction stay float32 either way.
         assert policy_dtype in ("f32", "bf16")
         self.pd = policy_dtype
+        # the two vocabulary-sized gradient products (G0 . W and G0^T . Hs, two fifths of the step's GEMM work):
+        # "f32x3" forms them from bf16 pieces of the operands at f32 rounding-level accuracy (hipabi.gemm)
+        assert vocab_grad_products in ("f32", "f32x3")
+        self.vgd = vocab_grad_products if policy_dtype == "f32" else policy_dtype
         # frozen_reward: the caller promises not to write to the reward network's parameters between steps
         # without calling parameters_changed(); what depends on them alone is then computed once
         self.frozen_reward, self._param_epoch = bool(frozen_reward), 0
@@ -1000,7 +1004,7 @@ class A2CEngine:
             stream.wait_event(ev)
             G0 = ws["dlogits"].view(s * n, self.vocab)   # left by the rollout's sampler launches
             hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ws["scratch_check"], b_kmajor=True, shared=True,
-                          dtype=self.pd)
+                          dtype=self.vgd)
             done = torch.cuda.Event()
             done.record(stream)
             self._mark("check:policy_early_done")
@@ -1331,7 +1335,7 @@ class A2CEngine:
         if ws.get("policy_early"):
             cur.wait_event(ws["ev_early"])
         else:
-            hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ss, b_kmajor=True, shared=True, dtype=self.pd)
+            hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ss, b_kmajor=True, shared=True, dtype=self.vgd)
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
@@ -1345,7 +1349,7 @@ class A2CEngine:
             other.wait_event(ev_scaled)
             sc, cs = (ws["scratch_check"], ws["cs_check"]) if other is not cur else (ss, ws["cs_side"])
             hip.gemm_auto(G0, ws["HsC"], gP["linear2vocab.weight"], sc, a_kmajor=True, b_kmajor=True, shared=True,
-                          dtype=self.pd)
+                          dtype=self.vgd)
             hip.colsum(G0, gP["linear2vocab.bias"], scratch=cs, row_scale=coef)
             ev_vocab = torch.cuda.Event()
             ev_vocab.record(other)

@@ -27,6 +27,10 @@ SIGNATURES = {
                                c_vp, c_vp, c_int, c_int, c_vp]),
     "icrl_gemm_bf16_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
                                       c_int, c_int, c_vp]),
+    "icrl_gemm_f32x3": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_int,
+                                c_vp, c_vp, c_int, c_int, c_vp]),
+    "icrl_gemm_f32x3_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
+                                       c_int, c_int, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 6),
@@ -222,7 +226,9 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
          m=None, n=None, k=None, lda=None, ldb=None, ldc=None, tile=0, dtype="f32"):
     """out[M,N] (+)= A[M,K] @ B[K,N] (+ bias + bias2).  tile: 0 = by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64.
     dtype "bf16": operands rounded to bf16 on chip, products on the bf16 matrix instruction, float32 sums
-    (tiles 1 and 3 only).
+    (tiles 1 and 3 only).  dtype "f32x3": every element cut into three bf16 pieces on chip, six piece products per
+    element product on the bf16 matrix instruction: f32 rounding-level accuracy at about twice the f32 kernel's rate
+    on long products (128x128 tiles only; no a_rows, no bias2).
 
     a: stored [M, K] (a_kmajor False) or [K, M] (True); b: stored [N, K] (False, an
     nn.Linear weight) or [K, N] (True).  2-D tensors whose last dimension is contiguous;
@@ -242,9 +248,11 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     ldc = out.stride(0) if ldc is None else ldc
     if a_rows is not None:
         assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
-    assert dtype in ("f32", "bf16")
+    assert dtype in ("f32", "bf16", "f32x3")
     if dtype == "bf16":
         fn, kind, tile = load().icrl_gemm_bf16, "gemm_bf16", (1 if tile == 2 else tile)
+    elif dtype == "f32x3":
+        fn, kind, tile = load().icrl_gemm_f32x3, "gemm_f32x3", 1
     else:
         fn, kind = load().icrl_gemm_f32, "gemm"
     with _Timed(kind, 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
@@ -480,6 +488,8 @@ def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0, 
     assert slabs.shape == (splits, m, n) and slabs.is_contiguous()
     if dtype == "bf16":
         fn, kind, tile = load().icrl_gemm_bf16_splitk, "gemm_bf16", (1 if tile == 2 else tile)
+    elif dtype == "f32x3":
+        fn, kind, tile = load().icrl_gemm_f32x3_splitk, "gemm_f32x3", 1
     else:
         fn, kind = load().icrl_gemm_f32_splitk, "gemm"
     with _Timed(kind, 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
@@ -556,6 +566,11 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         # the bf16 kernel's plans, from its own sweep: long k over large outputs in 128x128 tiles with k in four,
         # long k over small outputs in 64x64 tiles with k in two, k ~ 2000 unsplit in 64x64 tiles
         tile, splits = ((1, 4) if m * n >= (1 << 21) else (3, 2)) if k >= 4096 else (3, 1)
+    if dtype == "f32x3":
+        # 128x128 tiles, two workgroups per CU: the split whose workgroups fill whole turns of 512 places best
+        t128 = ((m + 127) // 128) * ((n + 127) // 128)
+        fits = [sp for sp in range(1, 9) if sp == 1 or k // sp >= 1024]
+        tile, splits = 1, min(fits, key=lambda sp: (-(-t128 * sp // 512) / (t128 * sp / 512.0), -sp))
     if splits > 1:  # no more partial slabs than the scratch buffer holds
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:

@@ -76,6 +76,20 @@ int icrl_gemm_bf16_splitk(const float* A, int64_t lda, int a_kmajor, const float
                           int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
                           int N, int K, int splits, int tile, icrl_stream_t stream);
 
+/* The same products once more, at close to f32 accuracy on the bf16 matrix instruction: every element is cut
+ * into three bf16 pieces (hi + mid + lo = the f32 value exactly) on its way into LDS and a product is the six
+ * piece products of weight 2^-16 and above, summed in f32 (the dropped ones are below 2^-23 of the product).
+ * Agrees with icrl_gemm_f32 to f32 rounding error, not bit for bit; about twice its rate on long products.
+ * 128x128 tiles (tile 0 or 1); no row gather, no second bias.  For the two vocabulary-sized gradient products
+ * of the policy network (autograd of models.py:82 at trainers.py:479). */
+int icrl_gemm_f32x3(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
+                    const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
+                    int M, int N, int K, const float* bias, const float* bias2,
+                    int accumulate, int tile, icrl_stream_t stream);
+int icrl_gemm_f32x3_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
+                           int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
+                           int N, int K, int splits, int tile, icrl_stream_t stream);
+
 /* out[i] = (accumulate ? out[i] : 0) + sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
 int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
                    int accumulate, icrl_stream_t stream);

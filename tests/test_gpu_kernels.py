@@ -742,3 +742,61 @@ def test_sampler_emits_onehot_minus_softmax_bit_equal_to_the_separate_pass(v, mo
     assert torch.equal(tok, tok2) and torch.equal(lp, lp2) and torch.equal(g0, want)
     with pytest.raises(RuntimeError, match="EMIT_DLOGITS"):
         hip.sample_tokens(logits, hip.GREEDY | hip.EMIT_DLOGITS, tok2, 1, probs=g0)
+
+
+# --------------------------------------------------------------------------- GEMM from three bf16 pieces per element
+@pytest.mark.parametrize("a_km", [False, True])
+@pytest.mark.parametrize("b_km", [False, True])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 130, 333), (77, 300, 2050), (256, 512, 37)])
+def test_f32x3_gemm_layouts(a_km, b_km, shape):
+    """icrl_gemm_f32x3: every element cut into three bf16 pieces, six piece products per element product, float32
+    sums.  Against a float64 product: within the exact-f32 kernel's own error bound (1e-7 * sum|a*b| per rounding,
+    here with the three dropped piece products on top); bias, accumulate, ragged edges, split-K slabs."""
+    m, n, k = shape
+    rs = np.random.RandomState(m + n + k + 1)
+    a = rnd(rs, *((k, m) if a_km else (m, k)))
+    b = rnd(rs, *((k, n) if b_km else (n, k)))
+    bias = rnd(rs, n)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    a64, b64 = (a64.T if a_km else a64), (b64 if b_km else b64.T)
+    want = a64 @ b64
+    tol = 6e-7 * (np.abs(a64) @ np.abs(b64)) + 1e-6
+    out = torch.full((m, n), 9.0, device="cuda")
+    hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, bias=dev(bias), dtype="f32x3")
+    assert np.all(np.abs(out.cpu().numpy() - (want + bias)) <= tol)
+    hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, accumulate=True, dtype="f32x3")
+    assert np.all(np.abs(out.cpu().numpy() - (2 * want + bias)) <= 2 * tol)
+    if k >= 300:
+        slabs = torch.zeros(3, m, n, device="cuda")
+        hip.gemm_splitk(dev(a), dev(b), slabs, 3, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+        hip.sum_slabs(slabs, out)
+        assert np.all(np.abs(out.cpu().numpy() - want) <= tol)
+    # the same product twice: the same bits (no atomics, fixed summation order)
+    again = torch.empty(m, n, device="cuda")
+    hip.gemm(dev(a), dev(b), again, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+    first = torch.empty(m, n, device="cuda")
+    hip.gemm(dev(a), dev(b), first, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+    assert torch.equal(first, again)
+
+
+@pytest.mark.parametrize("b_km", [False, True])
+def test_f32x3_pieces_add_up_to_the_element_exactly(b_km):
+    """hi + mid + lo is the float32 value bit for bit: a product with the identity returns the matrix itself,
+    over 60 binades of magnitudes, for both staging paths (k contiguous / rows contiguous) of each operand."""
+    rs = np.random.RandomState(3)
+    m, k = 150, 96
+    a = (rs.standard_normal((m, k)) * np.exp2(rs.randint(-30, 30, size=(m, k)))).astype(np.float32)
+    eye = dev(np.eye(k, dtype=np.float32))
+    for a_km in (False, True):
+        out = torch.empty(m, k, device="cuda")
+        hip.gemm(dev(a.T.copy() if a_km else a), eye, out, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+        assert np.array_equal(out.cpu().numpy(), a)
+        out_t = torch.empty(k, m, device="cuda")   # the matrix as the B operand
+        hip.gemm(eye, dev(a.T.copy() if b_km else a), out_t, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+        assert np.array_equal(out_t.cpu().numpy(), a.T)
+
+
+def test_f32x3_gemm_rejects_what_it_does_not_do():
+    a = torch.zeros(8, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="no row gather"):
+        hip.gemm(a, a, torch.zeros(8, 8, device="cuda"), bias=a[0], bias2=a[0], dtype="f32x3")
