@@ -145,8 +145,8 @@ def main():
     ap.add_argument("--policy-dtype", default="f32", choices=("f32", "bf16"),
                     help="bf16: the policy network's products on the bf16 matrix instruction (NOT the headline "
                          "workload's arithmetic: reported under its own workload name and dtype)")
-    ap.add_argument("--vocab-grad-products", default=None, choices=("f32", "f32x3"),
-                    help="how the two vocabulary-sized gradient products are formed (default: the engine's)")
+    ap.add_argument("--grad-products", default=None, choices=("f32", "f32x3"),
+                    help="how the backward pass forms its products over all positions (default: the engine's)")
     ap.add_argument("--value-forget-bias", type=float, default=0.0,
                     help="added to the value LSTM's forget-gate bias: a recurrence with a longer memory (stress case, "
                          "reported under its own workload name)")
@@ -183,8 +183,8 @@ def main():
         engine_opts["warm16"] = False
     if args.policy_dtype != "f32":
         engine_opts["policy_dtype"] = args.policy_dtype
-    if args.vocab_grad_products is not None:
-        engine_opts["vocab_grad_products"] = args.vocab_grad_products
+    if args.grad_products is not None:
+        engine_opts["grad_products"] = args.grad_products
     engine = trainers.build_engine(a2c, rew, **engine_opts)
     feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, rank)  # a different shard per rank
     feats_d = torch.from_numpy(feats).to(dev)
@@ -293,9 +293,9 @@ def main():
                 "frac_of_bf16_mfma_peak": bf / bs / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                 "algorithmic_bytes_per_launch": bb / max(1, bl)}
     x3 = None
-    if "gemm_f32x3" in acc:   # the two vocabulary-sized gradient products: six bf16 piece products per element product
+    if "gemm_f32x3" in acc:   # the backward pass's products over all positions: six bf16 piece products per element product
         xf, xs, xl, xb = acc["gemm_f32x3"]
-        x3 = {"kernel": "gemm_f32x3_kernel (G0 . W and G0^T . Hs of the policy network's backward pass)",
+        x3 = {"kernel": "gemm_f32x3_kernel (backward pass: G0 . W, G0^T . Hs, the recurrent layers' weight and input gradients)",
               "launches_per_step": xl, "gflop_per_step": xf / 1e9, "ms_per_step_in_kernel": 1e3 * xs,
               "achieved_tflops": xf / xs / 1e12, "frac_of_f32_mfma_peak": xf / xs / 1e12 / F32_MFMA_PEAK_TFLOPS,
               "bf16_mfma_tflops_issued": 6.0 * xf / xs / 1e12,
@@ -388,7 +388,7 @@ def main():
                                                   "kernels run one at a time (profiles/pmc_mfma.json)"},
             "bf16_gemms": bf16,
             "f32x3_gemms": x3,
-            "vocab_grad_products": engine.vgd,
+            "grad_products": engine.vgd,
             "chains": chains,
             "profiled_step": {"plans": profiled_plans, "no_attempt_redone": profiled_clean,
                               "note": "the roofline and chain figures are this step's launches, with this step's plans"},

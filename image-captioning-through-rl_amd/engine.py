@@ -182,7 +182,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
-                 frozen_reward=False, warm16=True, warm16_backward=False, vocab_grad_products="f32x3",
+                 frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f32x3",
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -204,10 +204,13 @@ class A2CEngine:
         # float32 sums.  The chains, heads, softmax / sampler and every reduction stay float32 either way.
         assert policy_dtype in ("f32", "bf16")
         self.pd = policy_dtype
-        # the two vocabulary-sized gradient products (G0 . W and G0^T . Hs, two fifths of the step's GEMM work):
-        # "f32x3" forms them from bf16 pieces of the operands at f32 rounding-level accuracy (hipabi.gemm)
-        assert vocab_grad_products in ("f32", "f32x3")
-        self.vgd = vocab_grad_products if policy_dtype == "f32" else policy_dtype
+        # the backward pass's products over all (step, row) positions - the two vocabulary-sized ones (G0 . W and
+        # G0^T . Hs, two fifths of the step's GEMM work) and the recurrent layers' weight and input gradients:
+        # "f32x3" forms them from bf16 pieces of the operands at f32 rounding-level accuracy (hipabi.gemm); what
+        # the forward pass computes (tokens, log-probabilities, values, rewards, the loss) stays on the exact kernel
+        assert grad_products in ("f32", "f32x3")
+        self.gd = grad_products                                               # value network
+        self.vgd = grad_products if policy_dtype == "f32" else policy_dtype   # policy network
         # frozen_reward: the caller promises not to write to the reward network's parameters between steps
         # without calling parameters_changed(); what depends on them alone is then computed once
         self.frozen_reward, self._param_epoch = bool(frozen_reward), 0
@@ -1231,7 +1234,7 @@ class A2CEngine:
         hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], scratch, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
         hip.colsum(dvalue, gV["linear2.bias"], scratch=cs)
         gw1 = gV["linear1.weight"]
-        hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, a_kmajor=True, b_kmajor=True, dtype=self.gd)
         gw1[:, self.F:].copy_(ws["gw1h"])
         hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1), scratch=cs)
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
@@ -1287,7 +1290,8 @@ class A2CEngine:
         back = n if plan[0] == "rows" else 1
         if tv > back:
             h_prev = saved.view(tv, 6 * H)[:tv - back, 5 * H:]
-            hip.gemm_auto(dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], sm, a_kmajor=True, b_kmajor=True)
+            hip.gemm_auto(dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], sm, a_kmajor=True, b_kmajor=True,
+                          dtype=self.gd)
         else:
             gV["valrnn.lstm.weight_hh_l0"].zero_()
         self._mark("value_wgrads_done")
@@ -1301,14 +1305,14 @@ class A2CEngine:
         if ev_loss is not None and not ws.pop("Xv_gathered", False):
             # the A2C step took its input projections from the per-word table: gather x now
             hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
-        hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], sm, a_kmajor=True, b_kmajor=True)
+        hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], sm, a_kmajor=True, b_kmajor=True, dtype=self.gd)
         hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_main"])
         gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
         g_emb = gV.get("valrnn.caption_embedding.weight")
         if g_emb is not None:
             if ws.get("ev_order_done") is not None:
                 main.wait_event(ws["ev_order_done"])
-            hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], sm, b_kmajor=True)
+            hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], sm, b_kmajor=True, dtype=self.gd)
             hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
         self._mark("value_input_grads_done")
         if ev_side is not None:
@@ -1366,14 +1370,15 @@ class A2CEngine:
         hip.policy_lstm_bptt(ws["gates"], ws["Cbuf"], dHall, P["lstm.weight_hh_l0"], dgp, ws["dc0"], ws["dc1"], ws["dh0"],
                              ss, shared=True, dtype=self.pd)
         dg_all = dgp.view(t_steps * n, 4 * H)
-        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
+        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True,
+                      shared=True, dtype=self.vgd)
         hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,
-                      b_kmajor=True, shared=True, dtype=self.pd)
+                      b_kmajor=True, shared=True, dtype=self.vgd)
         hip.colsum(dg_all, gP["lstm.bias_ih_l0"], scratch=ws["cs_side"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
-            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True, dtype=self.pd)
+            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True, dtype=self.vgd)
             hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
         hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])

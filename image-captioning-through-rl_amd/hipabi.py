@@ -569,7 +569,7 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
     if dtype == "f32x3":
         # 128x128 tiles, two workgroups per CU: the split whose workgroups fill whole turns of 512 places best
         t128 = ((m + 127) // 128) * ((n + 127) // 128)
-        fits = [sp for sp in range(1, 9) if sp == 1 or k // sp >= 1024]
+        fits = [sp for sp in range(1, 9) if sp == 1 or (contiguous and k // sp >= 512)]
         tile, splits = 1, min(fits, key=lambda sp: (-(-t128 * sp // 512) / (t128 * sp / 512.0), -sp))
     if splits > 1:  # no more partial slabs than the scratch buffer holds
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)

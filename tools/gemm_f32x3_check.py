@@ -30,6 +30,8 @@ def timed(fn, reps=10):
 
 # (M, N, K, a_kmajor, b_kmajor, f32 plan (tile, splits), what)
 for m, n, k, ka, kb, plan32, what in [(9728, 512, 10000, 0, 1, (3, 2), "G0 . W"), (10000, 512, 9728, 1, 1, (3, 2), "G0^T . Hs"),
+                                      (2048, 512, 9728, 1, 1, (3, 4), "dgates^T . X"), (9728, 512, 2048, 0, 1, (3, 2), "dgates . W_ih"),
+                                      (512, 2048, 9728, 1, 1, (3, 4), "X^T . dgates"),
                                       (1000, 300, 777, 0, 0, (3, 1), "edges"), (130, 260, 4100, 1, 0, (3, 1), "edges, a k-major")]:
     a = torch.randn((k, m) if ka else (m, k), generator=g).to(dev)
     b = torch.randn((k, n) if kb else (n, k), generator=g).to(dev)
@@ -55,7 +57,7 @@ for m, n, k, ka, kb, plan32, what in [(9728, 512, 10000, 0, 1, (3, 2), "G0 . W")
     scale = ref.abs().max().item()
     e32 = (out32.double() - ref).abs().max().item() / scale
     cells = []
-    for s in (1, 2, 4, 5, 6, 8):
+    for s in (1, 2, 4, 5, 6, 8, 12, 16):
         if k // s < 256:
             continue
 
