@@ -162,3 +162,28 @@ def test_bf16_policy_arithmetic_at_full_size(full_size):
         ref = fs["grads"][k]
         tol = 5e-2 if k.startswith("policy_network.") else 2e-2
         assert float((p.grad - ref).norm()) <= tol * float(ref.norm()) + 1e-9, (k, float((p.grad - ref).norm()), float(ref.norm()))
+
+
+def test_gradient_products_from_bf16_pieces_against_the_exact_kernel_at_full_size(full_size):
+    """The default engine forms the backward pass's long products (G0 . W, G0^T . Hs, the recurrent layers' weight
+    and input gradients) from three bf16 pieces per element; with grad_products="f32" they run on the exact-f32
+    kernel.  Nothing the forward pass computes may change (tokens, log-probs, values, rewards, loss scalars:
+    bit-equal), and every gradient agrees to 2e-6 of its L2 norm and element by element to 5e-6 of its largest entry -
+    float32 rounding of sums over 9 728 positions, not bf16 rounding (which is four orders of magnitude larger)."""
+    fs = full_size
+    assert fs["engine"].gd == "f32x3" and fs["engine"].vgd == "f32x3"
+    exact = trainers.build_engine(fs["a2c"], fs["rew"], grad_products="f32")
+    res = exact.step(*fs["args"], uniforms=torch.from_numpy(fs["u"]).cuda()).check()
+    torch.cuda.synchronize()
+    assert res.chain_plan == fs["plan"]
+    assert torch.equal(res.tokens, fs["tokens"]) and torch.equal(res.log_probs, fs["log_probs"])
+    assert torch.equal(res.values, fs["values"]) and torch.equal(res.rewards, fs["rewards"])
+    assert torch.equal(res.scalars[:5], fs["scalars"][:5])
+    differ = 0
+    for k, p in fs["a2c"].named_parameters():
+        got, want = fs["grads"][k], p.grad
+        differ += int(not torch.equal(got, want))
+        assert float((got - want).norm()) <= 2e-6 * float(want.norm()) + 1e-12, (k, float((got - want).norm()), float(want.norm()))
+        top = want.abs().max().item()
+        assert (got - want).abs().max().item() <= 5e-6 * top + 1e-12, (k, (got - want).abs().max().item(), top)
+    assert differ > 0   # the two engines really took different kernels
