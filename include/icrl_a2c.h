@@ -80,8 +80,10 @@ int icrl_gemm_bf16_splitk(const float* A, int64_t lda, int a_kmajor, const float
  * into three bf16 pieces (hi + mid + lo = the f32 value exactly) on its way into LDS and a product is the six
  * piece products of weight 2^-16 and above, summed in f32 (the dropped ones are below 2^-23 of the product).
  * Agrees with icrl_gemm_f32 to f32 rounding error, not bit for bit; about twice its rate on long products.
- * 128x128 tiles (tile 0 or 1); no row gather, no second bias.  For the two vocabulary-sized gradient products
- * of the policy network (autograd of models.py:82 at trainers.py:479). */
+ * tile: 1 = 128x128 (256 threads, 60 KB of LDS: two workgroups per CU, or one beside a persistent chain kernel),
+ * 2 = 256x128 (512 threads, 90 KB), 0 = 2 from 1024 rows on; no row gather, no second bias.  For the backward
+ * pass's products over all (step, row) positions: the two vocabulary-sized ones and the recurrent layers' weight
+ * and input gradients (autograd of models.py:80-82, 133 at trainers.py:479). */
 int icrl_gemm_f32x3(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,
                     const float* B, int64_t ldb, int b_kmajor, float* C, int64_t ldc,
                     int M, int N, int K, const float* bias, const float* bias2,

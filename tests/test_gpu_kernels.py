@@ -761,16 +761,17 @@ def test_f32x3_gemm_layouts(a_km, b_km, shape):
     a64, b64 = (a64.T if a_km else a64), (b64 if b_km else b64.T)
     want = a64 @ b64
     tol = 6e-7 * (np.abs(a64) @ np.abs(b64)) + 1e-6
-    out = torch.full((m, n), 9.0, device="cuda")
-    hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, bias=dev(bias), dtype="f32x3")
-    assert np.all(np.abs(out.cpu().numpy() - (want + bias)) <= tol)
-    hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, accumulate=True, dtype="f32x3")
-    assert np.all(np.abs(out.cpu().numpy() - (2 * want + bias)) <= 2 * tol)
-    if k >= 300:
-        slabs = torch.zeros(3, m, n, device="cuda")
-        hip.gemm_splitk(dev(a), dev(b), slabs, 3, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
-        hip.sum_slabs(slabs, out)
-        assert np.all(np.abs(out.cpu().numpy() - want) <= tol)
+    for tile in (1, 2):   # 128x128 tiles (256 threads), 256x128 tiles (512 threads)
+        out = torch.full((m, n), 9.0, device="cuda")
+        hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, bias=dev(bias), tile=tile, dtype="f32x3")
+        assert np.all(np.abs(out.cpu().numpy() - (want + bias)) <= tol)
+        hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, accumulate=True, tile=tile, dtype="f32x3")
+        assert np.all(np.abs(out.cpu().numpy() - (2 * want + bias)) <= 2 * tol)
+        if k >= 300:
+            slabs = torch.zeros(3, m, n, device="cuda")
+            hip.gemm_splitk(dev(a), dev(b), slabs, 3, a_kmajor=a_km, b_kmajor=b_km, tile=tile, dtype="f32x3")
+            hip.sum_slabs(slabs, out)
+            assert np.all(np.abs(out.cpu().numpy() - want) <= tol)
     # the same product twice: the same bits (no atomics, fixed summation order)
     again = torch.empty(m, n, device="cuda")
     hip.gemm(dev(a), dev(b), again, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
@@ -787,12 +788,12 @@ def test_f32x3_pieces_add_up_to_the_element_exactly(b_km):
     m, k = 150, 96
     a = (rs.standard_normal((m, k)) * np.exp2(rs.randint(-30, 30, size=(m, k)))).astype(np.float32)
     eye = dev(np.eye(k, dtype=np.float32))
-    for a_km in (False, True):
+    for a_km, tile in ((False, 1), (True, 1), (False, 2), (True, 2)):
         out = torch.empty(m, k, device="cuda")
-        hip.gemm(dev(a.T.copy() if a_km else a), eye, out, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+        hip.gemm(dev(a.T.copy() if a_km else a), eye, out, a_kmajor=a_km, b_kmajor=b_km, tile=tile, dtype="f32x3")
         assert np.array_equal(out.cpu().numpy(), a)
         out_t = torch.empty(k, m, device="cuda")   # the matrix as the B operand
-        hip.gemm(eye, dev(a.T.copy() if b_km else a), out_t, a_kmajor=a_km, b_kmajor=b_km, dtype="f32x3")
+        hip.gemm(eye, dev(a.T.copy() if b_km else a), out_t, a_kmajor=a_km, b_kmajor=b_km, tile=tile, dtype="f32x3")
         assert np.array_equal(out_t.cpu().numpy(), a.T)
 
 

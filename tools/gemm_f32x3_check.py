@@ -32,6 +32,8 @@ def timed(fn, reps=10):
 for m, n, k, ka, kb, plan32, what in [(9728, 512, 10000, 0, 1, (3, 2), "G0 . W"), (10000, 512, 9728, 1, 1, (3, 2), "G0^T . Hs"),
                                       (2048, 512, 9728, 1, 1, (3, 4), "dgates^T . X"), (9728, 512, 2048, 0, 1, (3, 2), "dgates . W_ih"),
                                       (512, 2048, 9728, 1, 1, (3, 4), "X^T . dgates"),
+                                      (512, 12048, 512, 0, 0, (3, 1), "logits | h.W_hh"), (10000, 2048, 512, 0, 0, (3, 1), "per-word table"),
+                                      (9728, 512, 512, 0, 0, (3, 1), "chain input products"),
                                       (1000, 300, 777, 0, 0, (3, 1), "edges"), (130, 260, 4100, 1, 0, (3, 1), "edges, a k-major")]:
     a = torch.randn((k, m) if ka else (m, k), generator=g).to(dev)
     b = torch.randn((k, n) if kb else (n, k), generator=g).to(dev)
@@ -57,19 +59,23 @@ for m, n, k, ka, kb, plan32, what in [(9728, 512, 10000, 0, 1, (3, 2), "G0 . W")
     scale = ref.abs().max().item()
     e32 = (out32.double() - ref).abs().max().item() / scale
     cells = []
-    for s in (1, 2, 4, 5, 6, 8, 12, 16):
-        if k // s < 256:
-            continue
+    for tile in (1, 2):
+        best = None
+        for s in (1, 2, 3, 4, 5, 6, 8):
+            if k // s < 256:
+                continue
 
-        def runx3():
-            if s > 1:
-                slabs = scratch[:s * m * n].view(s, m, n)
-                hip.gemm_splitk(a, b, slabs, s, a_kmajor=bool(ka), b_kmajor=bool(kb), dtype="f32x3")
-                hip.sum_slabs(slabs, outx3)
-            else:
-                hip.gemm(a, b, outx3, a_kmajor=bool(ka), b_kmajor=bool(kb), dtype="f32x3")
+            def runx3():
+                if s > 1:
+                    slabs = scratch[:s * m * n].view(s, m, n)
+                    hip.gemm_splitk(a, b, slabs, s, a_kmajor=bool(ka), b_kmajor=bool(kb), tile=tile, dtype="f32x3")
+                    hip.sum_slabs(slabs, outx3)
+                else:
+                    hip.gemm(a, b, outx3, a_kmajor=bool(ka), b_kmajor=bool(kb), tile=tile, dtype="f32x3")
 
-        tx = timed(runx3)
-        ex = (outx3.double() - ref).abs().max().item() / scale
-        cells.append("k/%d %7.1f us err %.1e" % (s, tx, ex))
+            tx = timed(runx3)
+            ex = (outx3.double() - ref).abs().max().item() / scale
+            if best is None or tx < best[0]:
+                best = (tx, s, ex)
+        cells.append("%s best k/%d %7.1f us err %.1e" % ("128x128" if tile == 1 else "256x128", best[1], best[0], best[2]))
     print("%6d %6d %6d %d %d  f32 %7.1f us err %.1e | f32x3 %s   %s" % (m, n, k, ka, kb, t32, e32, "  ".join(cells), what))
