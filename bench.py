@@ -255,7 +255,7 @@ def main():
     # bracketed by HIP events.  In the timed steps the GEMM launches share the CUs with the chain kernels and
     # with each other (three streams), so their durations there say how the step is packed, not how good the
     # kernel is; this pass gives the kernel's own figure for the very same shapes.
-    one_stream = None
+    one_stream = x3_alone = None
     if world == 1:
         engine.concurrent = False
         one_step(total_steps - 2)
@@ -273,6 +273,13 @@ def main():
                           "ms_in_kernel": 1e3 * se,
                           "note": "the step's gemm_f32_kernel launches with every launch of the minibatch on one "
                                   "stream (nothing runs beside them), HIP events around each"}
+
+        fx = sum(r[1] for r in alone if r[0] == "gemm_f32x3")
+        sx = sum(r[2].elapsed_time(r[3]) for r in alone if r[0] == "gemm_f32x3") * 1e-3
+        x3_alone = None if sx <= 0 else {
+            "achieved_tflops": fx / sx / 1e12, "frac_of_f32_mfma_peak": fx / sx / 1e12 / F32_MFMA_PEAK_TFLOPS,
+            "frac_of_bf16_mfma_peak": 6.0 * fx / sx / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "launches": sum(1 for r in alone if r[0] == "gemm_f32x3"), "gflop": fx / 1e9, "ms_in_kernel": 1e3 * sx}
 
     # ---- per-kernel accounting of the profiled step from the HIP events recorded on each launch's own stream
     acc, chain_steps, chain_flops = {}, {}, {}
@@ -300,7 +307,7 @@ def main():
               "achieved_tflops": xf / xs / 1e12, "frac_of_f32_mfma_peak": xf / xs / 1e12 / F32_MFMA_PEAK_TFLOPS,
               "bf16_mfma_tflops_issued": 6.0 * xf / xs / 1e12,
               "frac_of_bf16_mfma_peak": 6.0 * xf / xs / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-              "algorithmic_bytes_per_launch": xb / max(1, xl),
+              "algorithmic_bytes_per_launch": xb / max(1, xl), "one_stream": x3_alone,
               "note": "element products counted once (2 M N K); every one is six v_mfma_f32_32x32x16_bf16 piece "
                       "products, f32 sums, f32 rounding-level accuracy"}
     peak = F32_MFMA_PEAK_TFLOPS
