@@ -4,12 +4,15 @@
 //     a.b ~ hi.hi + (hi.mid + mid.hi) + (mid.mid + hi.lo + lo.hi),
 // summed in f32 by v_mfma_f32_32x32x16_bf16 (every piece product is exact; what is dropped, mid.lo + lo.mid +
 // lo.lo, is below 2^-23 of |a.b|, the size of one f32 rounding of the product).  Six bf16 instructions do the work
-// of sixteen v_mfma_f32_32x32x2_f32, so a long product runs at about twice the exact-f32 kernel's rate; sums
-// are accumulated in a different order and with different roundings than there, so results agree to f32 rounding
-// error, not bit for bit.  Used for the two vocabulary-sized gradient products of the policy network.
+// of sixteen v_mfma_f32_32x32x2_f32 (3/8 of the matrix units' cycles), and a long product runs 1.3-1.5 times as
+// fast as on the exact-f32 kernel: what bounds it is the delivery of its f32 operands to the CUs (two 128-wide
+// tile edges per 128 x 128 x 32 stage).  Sums are accumulated in a different order and with different roundings
+// than there, so results agree to f32 rounding error, not bit for bit.  Used for the backward pass's products over
+// all (step, row) positions: the two vocabulary-sized ones and the recurrent layers' weight and input gradients.
 //
-// Same calling convention, operand layouts, split-K slabs and XCD-aware tile order as gemm_f32.hip; 128x128
-// tiles, k stages of 32, LDS images as in gemm_bf16.hip (three of them per operand), two workgroups per CU.
+// Same calling convention, operand layouts, split-K slabs and XCD-aware tile order as gemm_f32.hip; 128x128 tiles
+// on 256 threads (two workgroups per CU, or one beside a persistent chain workgroup) or 256x128 on 512, one wave
+// per 64 x 64 of the tile; k stages of 32; LDS rows of k as in gemm_bf16.hip, three images per operand.
 #include "icrl_common.h"
 
 namespace {
