@@ -11,8 +11,10 @@
 // all (step, row) positions: the two vocabulary-sized ones and the recurrent layers' weight and input gradients.
 //
 // Same calling convention, operand layouts, split-K slabs and XCD-aware tile order as gemm_f32.hip; 128x128 tiles
-// on 256 threads (two workgroups per CU, or one beside a persistent chain workgroup) or 256x128 on 512, one wave
-// per 64 x 64 of the tile; k stages of 32; LDS rows of k as in gemm_bf16.hip, three images per operand.
+// on 256 threads, one wave per 64 x 64 of the tile; k stages of 16 with four stages of global loads in flight in
+// registers; LDS rows of k as in gemm_bf16.hip, three images per operand, one stage at a time: 36 KB per
+// workgroup, so that four fit a CU and two fit beside a persistent chain workgroup (which leaves 76-80 KB).  With
+// 32-deep stages (60 KB) the same loop ran 5-15 % slower at two per CU and 1.4 times slower where only one fits.
 #include "icrl_common.h"
 
 namespace {
@@ -21,9 +23,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 8;   // bf16 elements per LDS row (20 dwords: the ds_read_b128 of 16 rows at one k offset is conflict-free)
-constexpr int BN = 128;   // tile columns; tile rows BM = 128 (256 threads, two workgroups per CU) or 256 (512 threads, one)
+constexpr int BK = 16;
+constexpr int LDK = BK + 8;   // bf16 elements per LDS row (12 dwords: the ds_read_b128 of 16 rows at one k offset is conflict-free)
+constexpr int BM = 128, BN = 128, NT = 256;
+constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;      // one piece's image of an operand tile (bf16 elements)
+constexpr int BUF = 3 * (A_PLANE + B_PLANE);               // one stage: A hi, mid, lo, B hi, mid, lo (36 KB)
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -45,13 +49,13 @@ __device__ __forceinline__ void split3(float x, float y, unsigned& hi, unsigned&
 
 // Staging of one operand tile of ROWS x BK: global -> registers (load), registers -> three LDS images [row][k]
 // `plane` elements apart (store3).
-// KM = false (k contiguous in memory, [rows][ld]): piece i of thread tid is row f / 8, k quad f % 8, f = tid + NT i:
+// KM = false (k contiguous in memory, [rows][ld]): piece i of thread tid is row f / 4, k quad f % 4, f = tid + NT i:
 // one float4, stored as three 8-byte pieces.
 // KM = true (rows contiguous in memory, [K][ld]): piece i is row f % ROWS, k octet f / ROWS: eight dword loads, each
 // of them 64 consecutive rows per wave, stored as three 16-byte pieces (eight lanes of a store hit eight different
 // bank groups; a thread that owned four rows of one k, as float4 loads along the rows would have it, puts the
 // lanes of a store four rows apart, which with rows a multiple of 16 bytes apart is two banks for all of them).
-template <int ROWS, bool KM, int NT>
+template <int ROWS, bool KM>
 struct Stage {
     static constexpr int PIECES = KM ? ROWS * BK / 8 / NT : ROWS * BK / 4 / NT;
     static_assert(PIECES >= 1 && PIECES * NT * (KM ? 8 : 4) == ROWS * BK, "the tile divides among the threads");
@@ -64,7 +68,7 @@ struct Stage {
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + NT * i;
             if (!KM) {
-                const int gr = row0 + f / 8, gk = k0 + 4 * (f % 8);
+                const int gr = row0 + f / (BK / 4), gk = k0 + 4 * (f % (BK / 4));
                 const float* p = base + (int64_t)gr * ld + gk;
                 if (!EDGE) {
                     const float4 v = *reinterpret_cast<const float4*>(p);
@@ -90,7 +94,7 @@ struct Stage {
                 uint2 w[3];
                 split3(x[i][0], x[i][1], w[0].x, w[1].x, w[2].x);
                 split3(x[i][2], x[i][3], w[0].y, w[1].y, w[2].y);
-                __bf16* dst = lds + (f / 8) * LDK + 4 * (f % 8);
+                __bf16* dst = lds + (f / (BK / 4)) * LDK + 4 * (f % (BK / 4));
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = w[p];
             } else {
@@ -125,26 +129,24 @@ struct GemmArgs {
     int64_t slab;      // C offset (floats) between split-K partial results
 };
 
-template <int BM, bool A_KM, bool B_KM, bool EDGE>
+template <bool A_KM, bool B_KM, bool EDGE>
 __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], __bf16* lds, int m0, int n0, int kbeg,
                                        int kend, int nk, int tid) {
-    constexpr int NT = 2 * BM;                                 // one wave per 64 x 64 of the tile
-    constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;      // one piece's image of an operand tile (bf16 elements)
-    constexpr int DEPTH = 2;   // stages in flight in registers
+    constexpr int DEPTH = 4;   // stages in flight in registers
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    Stage<BM, A_KM, NT> sa[DEPTH];
-    Stage<BN, B_KM, NT> sb[DEPTH];
+    Stage<BM, A_KM> sa[DEPTH];
+    Stage<BN, B_KM> sb[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (d < nk) {
             sa[d].template load<EDGE>(g.A, g.lda, m0, g.M, kbeg + d * BK, kend, tid);
             sb[d].template load<EDGE>(g.B, g.ldb, n0, g.N, kbeg + d * BK, kend, tid);
         }
-    // One LDS image of a stage (60 KB at 128 tile rows, so that two workgroups share a CU: while one multiplies, the
-    // other cuts its next stage into pieces and writes it; 90 KB at 256 rows).  Two barriers per stage: after the
-    // last reads of the stage before, after the writes of this one.
+    // One LDS image of a stage, several workgroups per CU: while one multiplies, another cuts its next stage into
+    // pieces and writes it.  Two barriers per stage: after the last reads of the stage before, after the writes
+    // of this one.
     for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -188,9 +190,9 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], _
     }
 }
 
-template <int BM, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(2 * BM) void gemm_f32x3_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // 3 * (BM + BN) * LDK elements
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -242,13 +244,13 @@ __global__ __launch_bounds__(2 * BM) void gemm_f32x3_kernel(GemmArgs g) {
     const bool interior = aligned && m0 + BM <= g.M && n0 + BN <= g.N;
     const int full = (kend - kbeg) / BK;
     if (interior && full > 0) {
-        k_loop<BM, A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
+        k_loop<A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
         if (full < nk) {
             __syncthreads();
-            k_loop<BM, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
+            k_loop<A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
         }
     } else if (nk > 0) {
-        k_loop<BM, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
+        k_loop<A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
@@ -272,37 +274,18 @@ __global__ __launch_bounds__(2 * BM) void gemm_f32x3_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, bool A_KM, bool B_KM>
+template <bool A_KM, bool B_KM>
 int launch_one(const GemmArgs& g, int splits, hipStream_t st) {
-    constexpr int kLds = 3 * (BM + BN) * LDK * (int)sizeof(__bf16);   // 60 KB / 90 KB
-    if (kLds > 64 * 1024) {   // above what a kernel gets without asking
-        static unsigned long long raised = 0;   // devices on which this instantiation's limit has been raised
-        int dev = 0;
-        ICRL_HIP(hipGetDevice(&dev));
-        if (dev >= 64 || !((raised >> dev) & 1)) {
-            ICRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32x3_kernel<BM, A_KM, B_KM>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-            if (dev < 64) raised |= 1ull << dev;
-        }
-    }
     const dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * splits);
-    hipLaunchKernelGGL((gemm_f32x3_kernel<BM, A_KM, B_KM>), grid, dim3(2 * BM), kLds, st, g);
+    hipLaunchKernelGGL((gemm_f32x3_kernel<A_KM, B_KM>), grid, dim3(NT), 0, st, g);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
-}
-
-template <int BM>
-int launch(const GemmArgs& g, int a_kmajor, int b_kmajor, int splits, hipStream_t st) {
-    if (!a_kmajor && !b_kmajor) return launch_one<BM, false, false>(g, splits, st);
-    if (!a_kmajor && b_kmajor) return launch_one<BM, false, true>(g, splits, st);
-    if (a_kmajor && !b_kmajor) return launch_one<BM, true, false>(g, splits, st);
-    return launch_one<BM, true, true>(g, splits, st);
 }
 
 int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
              int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int splits, int64_t slab, int tile,
              hipStream_t st, const char* who) {
-    ICRL_REQUIRE(tile >= 0 && tile <= 2, "%s: tile must be 0 (by shape), 1 (128x128) or 2 (256x128)", who);
+    ICRL_REQUIRE(tile == 0 || tile == 1, "%s: tile must be 0 or 1 (128x128)", who);
     ICRL_REQUIRE(A && B && C, "%s: null operand", who);
     ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty shape %dx%dx%d", who, M, N, K);
     ICRL_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N,
@@ -314,8 +297,10 @@ int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t 
     const int ksteps = (K + BK - 1) / BK;
     g.kchunk = ((ksteps + splits - 1) / splits) * BK;
     g.slab = slab;
-    if (tile == 0) tile = M >= 1024 ? 2 : 1;
-    return tile == 2 ? launch<256>(g, a_kmajor, b_kmajor, splits, st) : launch<128>(g, a_kmajor, b_kmajor, splits, st);
+    if (!a_kmajor && !b_kmajor) return launch_one<false, false>(g, splits, st);
+    if (!a_kmajor && b_kmajor) return launch_one<false, true>(g, splits, st);
+    if (a_kmajor && !b_kmajor) return launch_one<true, false>(g, splits, st);
+    return launch_one<true, true>(g, splits, st);
 }
 
 }  // namespace

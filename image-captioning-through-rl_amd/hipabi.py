@@ -228,7 +228,7 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     dtype "bf16": operands rounded to bf16 on chip, products on the bf16 matrix instruction, float32 sums
     (tiles 1 and 3 only).  dtype "f32x3": every element cut into three bf16 pieces on chip, six piece products per
     element product on the bf16 matrix instruction: f32 rounding-level accuracy at about twice the f32 kernel's rate
-    on long products (tile 1 = 128x128, 2 = 256x128, 0 = by the number of rows; no a_rows, no bias2).
+    on long products (128x128 tiles only; no a_rows, no bias2).
 
     a: stored [M, K] (a_kmajor False) or [K, M] (True); b: stored [N, K] (False, an
     nn.Linear weight) or [K, N] (True).  2-D tensors whose last dimension is contiguous;
@@ -252,7 +252,7 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     if dtype == "bf16":
         fn, kind, tile = load().icrl_gemm_bf16, "gemm_bf16", (1 if tile == 2 else tile)
     elif dtype == "f32x3":
-        fn, kind, tile = load().icrl_gemm_f32x3, "gemm_f32x3", (tile if tile in (1, 2) else 0)
+        fn, kind, tile = load().icrl_gemm_f32x3, "gemm_f32x3", 1
     else:
         fn, kind = load().icrl_gemm_f32, "gemm"
     with _Timed(kind, 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
@@ -489,7 +489,7 @@ def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0, 
     if dtype == "bf16":
         fn, kind, tile = load().icrl_gemm_bf16_splitk, "gemm_bf16", (1 if tile == 2 else tile)
     elif dtype == "f32x3":
-        fn, kind, tile = load().icrl_gemm_f32x3_splitk, "gemm_f32x3", (tile if tile in (1, 2) else 0)
+        fn, kind, tile = load().icrl_gemm_f32x3_splitk, "gemm_f32x3", 1
     else:
         fn, kind = load().icrl_gemm_f32_splitk, "gemm"
     with _Timed(kind, 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
@@ -567,14 +567,12 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         # long k over small outputs in 64x64 tiles with k in two, k ~ 2000 unsplit in 64x64 tiles
         tile, splits = ((1, 4) if m * n >= (1 << 21) else (3, 2)) if k >= 4096 else (3, 1)
     if dtype == "f32x3":
-        # 256x128 tiles, one workgroup per CU (90 KB of LDS); 128x128 tiles (60 KB, two per CU) for outputs of fewer
-        # than 1024 rows and beside a persistent chain kernel, whose workgroup leaves 76-80 KB of its CU's LDS: one
-        # such workgroup fits there, the larger tile would wait for the chain to end.  The split is the one whose
-        # workgroups fill whole turns of those places best.
-        tile, rows, places = (1, 128, 256) if shared else (2, 256, 256) if m >= 1024 else (1, 128, 512)
-        tiles = ((m + rows - 1) // rows) * ((n + 127) // 128)
+        # 128x128 tiles, 36 KB of LDS each: two workgroups fit a CU beside a persistent chain workgroup and the kernel
+        # runs as fast at two or three per CU as at four, so the split is the one whose workgroups fill whole turns
+        # of 512 places best (measured: k in five for 304 tiles, in eight for 316 and for 64)
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
         fits = [sp for sp in range(1, 9) if sp == 1 or (contiguous and k // sp >= 512)]
-        splits = min(fits, key=lambda sp: (-(-tiles * sp // places) / (tiles * sp / float(places)), -sp))
+        tile, splits = 1, min(fits, key=lambda sp: (-(-tiles * sp // 512) / (tiles * sp / 512.0), -sp))
     if splits > 1:  # no more partial slabs than the scratch buffer holds
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:

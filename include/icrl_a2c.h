@@ -80,8 +80,8 @@ int icrl_gemm_bf16_splitk(const float* A, int64_t lda, int a_kmajor, const float
  * into three bf16 pieces (hi + mid + lo = the f32 value exactly) on its way into LDS and a product is the six
  * piece products of weight 2^-16 and above, summed in f32 (the dropped ones are below 2^-23 of the product).
  * Agrees with icrl_gemm_f32 to f32 rounding error, not bit for bit; about twice its rate on long products.
- * tile: 1 = 128x128 (256 threads, 60 KB of LDS: two workgroups per CU, or one beside a persistent chain kernel),
- * 2 = 256x128 (512 threads, 90 KB), 0 = 2 from 1024 rows on; no row gather, no second bias.  For the backward
+ * 128x128 tiles (tile 0 or 1; 256 threads, 36 KB of LDS: four workgroups per CU, two beside a persistent chain
+ * kernel); no row gather, no second bias.  For the backward
  * pass's products over all (step, row) positions: the two vocabulary-sized ones and the recurrent layers' weight
  * and input gradients (autograd of models.py:80-82, 133 at trainers.py:479). */
 int icrl_gemm_f32x3(const float* A, int64_t lda, int a_kmajor, const int64_t* a_rows,

@@ -761,7 +761,7 @@ def test_f32x3_gemm_layouts(a_km, b_km, shape):
     a64, b64 = (a64.T if a_km else a64), (b64 if b_km else b64.T)
     want = a64 @ b64
     tol = 6e-7 * (np.abs(a64) @ np.abs(b64)) + 1e-6
-    for tile in (1, 2):   # 128x128 tiles (256 threads), 256x128 tiles (512 threads)
+    for tile in (0, 1):   # (one tile shape: 128x128)
         out = torch.full((m, n), 9.0, device="cuda")
         hip.gemm(dev(a), dev(b), out, a_kmajor=a_km, b_kmajor=b_km, bias=dev(bias), tile=tile, dtype="f32x3")
         assert np.all(np.abs(out.cpu().numpy() - (want + bias)) <= tol)
@@ -788,7 +788,7 @@ def test_f32x3_pieces_add_up_to_the_element_exactly(b_km):
     m, k = 150, 96
     a = (rs.standard_normal((m, k)) * np.exp2(rs.randint(-30, 30, size=(m, k)))).astype(np.float32)
     eye = dev(np.eye(k, dtype=np.float32))
-    for a_km, tile in ((False, 1), (True, 1), (False, 2), (True, 2)):
+    for a_km, tile in ((False, 1), (True, 1)):
         out = torch.empty(m, k, device="cuda")
         hip.gemm(dev(a.T.copy() if a_km else a), eye, out, a_kmajor=a_km, b_kmajor=b_km, tile=tile, dtype="f32x3")
         assert np.array_equal(out.cpu().numpy(), a)

@@ -59,7 +59,7 @@ for m, n, k, ka, kb, plan32, what in [(9728, 512, 10000, 0, 1, (3, 2), "G0 . W")
     scale = ref.abs().max().item()
     e32 = (out32.double() - ref).abs().max().item() / scale
     cells = []
-    for tile in (1, 2):
+    for tile in (1,):
         best = None
         for s in (1, 2, 3, 4, 5, 6, 8):
             if k // s < 256:
@@ -77,5 +77,5 @@ for m, n, k, ka, kb, plan32, what in [(9728, 512, 10000, 0, 1, (3, 2), "G0 . W")
             ex = (outx3.double() - ref).abs().max().item() / scale
             if best is None or tx < best[0]:
                 best = (tx, s, ex)
-        cells.append("%s best k/%d %7.1f us err %.1e" % ("128x128" if tile == 1 else "256x128", best[1], best[0], best[2]))
+        cells.append("best k/%d %7.1f us err %.1e" % (best[1], best[0], best[2]))
     print("%6d %6d %6d %d %d  f32 %7.1f us err %.1e | f32x3 %s   %s" % (m, n, k, ka, kb, t32, e32, "  ".join(cells), what))
