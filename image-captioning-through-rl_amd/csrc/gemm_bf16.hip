@@ -8,9 +8,11 @@
 // bf16 arithmetic; the recurrent chains never use it.
 //
 // LDS image, both operands: [row][k] bf16 with k contiguous, rows padded to 72 elements (36 dwords: the
-// ds_read_b128 of 16 rows at one k offset is conflict-free), 16-byte chunks permuted per group of 16 rows (swz).  A k-contiguous source ("MK": [rows][ld]) is
+// ds_read_b128 of 16 rows at one k offset is conflict-free).  A k-contiguous source ("MK": [rows][ld]) is
 // staged float4 -> 4 bf16 -> one 8-byte store; a row-contiguous source ("KM": [K][ld]) is transposed on the
-// way: a thread loads the float4 of rows r..r+3 at k and at k+1 and stores four 4-byte {k, k+1} pairs.
+// way: a thread owns one row and eight consecutive k (eight dword loads, each of them 64 consecutive rows per
+// wave) and stores one 16-byte piece, so that the eight lanes of a store hit eight different bank groups
+// (float4 loads along the rows would put the lanes of a store four rows apart: two banks for all of them).
 // Fragment of lane (r = lane & 31, h = lane >> 5) for k-step s of 16: elements k = 16s + 8h + j, j = 0..7 of
 // row r: one ds_read_b128.
 #include "icrl_common.h"
@@ -35,11 +37,6 @@ struct GemmArgs {
     int64_t slab;      // C offset (floats) between split-K partial results
 };
 
-// The 16-byte chunks (8 bf16) of an LDS row are permuted by the row's group of 16: chunk c of row r sits at
-// c ^ ((r >> 4) & 3).  Reads of 16 consecutive rows at one chunk stay conflict-free, and the transposing stores
-// of a row-contiguous source spread over all banks.
-__device__ __forceinline__ int swz(int row) { return (row >> 4) & 3; }
-
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     bf16x2 p;
@@ -49,73 +46,36 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 }
 
 // Staging of one operand tile of ROWS x BK.  KM = false: piece i of thread tid is row (f >> 4), k quad (f & 15),
-// f = tid + 256 i.  KM = true: piece i is the k pair (f / (ROWS/4)), row quad (f % (ROWS/4)): two float4.
+// f = tid + 256 i: one float4.  KM = true: piece i is row f % ROWS, k octet f / ROWS: eight floats.
 template <int ROWS, bool KM>
 struct Stage {
     static constexpr int PIECES = KM ? ROWS * BK / 8 / 256 : ROWS * BK / 4 / 256;
-    float4 r[KM ? 2 * PIECES : PIECES];
+    float x[PIECES][KM ? 8 : 4];
 
     // EDGE = false: the tile lies inside the matrix, rows are not gathered and every float4 is aligned: plain
     // loads, no branches (so that the compiler can keep several stages' loads outstanding).
     template <bool EDGE>
     __device__ __forceinline__ void load(const float* base, int64_t ld, const int64_t* gather, int row0, int nrows,
                                          int k0, int kend, int tid) {
-        if (!EDGE) {
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                const int f = tid + 256 * i;
-                if (!KM) {
-                    const int row = f >> 4, kq = f & 15;
-                    r[i] = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + row) * ld + k0 + 4 * kq);
-                } else {
-                    const int kp = f / (ROWS / 4), m4 = f % (ROWS / 4);
-                    const float* p = base + (int64_t)(k0 + 2 * kp) * ld + row0 + 4 * m4;
-                    r[2 * i] = *reinterpret_cast<const float4*>(p);
-                    r[2 * i + 1] = *reinterpret_cast<const float4*>(p + ld);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + 256 * i;
             if (!KM) {
-                const int row = f >> 4, kq = f & 15;
-                const int gr = row0 + row, gk = k0 + 4 * kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < nrows && gk < kend) {
-                    const int64_t src = gather ? gather[gr] : (int64_t)gr;
+                const int gr = row0 + (f >> 4), gk = k0 + 4 * (f & 15);
+                if (!EDGE) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)gr * ld + gk);
+                    x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
+                } else {
+                    const int64_t src = (gr < nrows && gather) ? gather[gr] : (int64_t)gr;
                     const float* p = base + src * ld + gk;
-                    if (gk + 4 <= kend && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-                        v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        v.x = p[0];
-                        if (gk + 1 < kend) v.y = p[1];
-                        if (gk + 2 < kend) v.z = p[2];
-                        if (gk + 3 < kend) v.w = p[3];
-                    }
-                }
-                r[i] = v;
-            } else {
-                const int kp = f / (ROWS / 4), m4 = f % (ROWS / 4);
-                const int gr = row0 + 4 * m4;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int gk = k0 + 2 * kp + e;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gk < kend && gr < nrows) {
-                        const float* p = base + (int64_t)gk * ld + gr;
-                        if (gr + 4 <= nrows && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-                            v = *reinterpret_cast<const float4*>(p);
-                        } else {
-                            v.x = p[0];
-                            if (gr + 1 < nrows) v.y = p[1];
-                            if (gr + 2 < nrows) v.z = p[2];
-                            if (gr + 3 < nrows) v.w = p[3];
-                        }
-                    }
-                    r[2 * i + e] = v;
+                    for (int e = 0; e < 4; ++e) x[i][e] = (gr < nrows && gk + e < kend) ? p[e] : 0.f;
                 }
+            } else {
+                const int gr = row0 + f % ROWS, gk = k0 + 8 * (f / ROWS);
+                const float* p = base + (int64_t)gk * ld + gr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[i][e] = (!EDGE || (gr < nrows && gk + e < kend)) ? p[e * ld] : 0.f;
             }
         }
     }
@@ -125,28 +85,22 @@ struct Stage {
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + 256 * i;
             if (!KM) {
-                const int row = f >> 4, kq = f & 15;
                 uint2 w;
-                w.x = pack2(r[i].x, r[i].y);
-                w.y = pack2(r[i].z, r[i].w);
-                *reinterpret_cast<uint2*>(lds + row * LDK + 8 * ((kq >> 1) ^ swz(row)) + 4 * (kq & 1)) = w;
+                w.x = pack2(x[i][0], x[i][1]);
+                w.y = pack2(x[i][2], x[i][3]);
+                *reinterpret_cast<uint2*>(lds + (f >> 4) * LDK + 4 * (f & 15)) = w;
             } else {
-                const int kp = f / (ROWS / 4), m4 = f % (ROWS / 4);
-                const float4 a = r[2 * i], b = r[2 * i + 1];
-                // rows 4 m4 .. 4 m4 + 3 share one swizzle; with it the 64 lanes' 4-byte stores (16 row quads x
-                // 4 k pairs) fall into 64 different banks (unswizzled: 4 lanes per bank)
-                unsigned* dst = reinterpret_cast<unsigned*>(lds + (4 * m4) * LDK + 8 * ((kp >> 2) ^ swz(4 * m4)) + 2 * (kp & 3));
-                dst[0] = pack2(a.x, b.x);
-                dst[LDK / 2] = pack2(a.y, b.y);
-                dst[LDK] = pack2(a.z, b.z);
-                dst[3 * LDK / 2] = pack2(a.w, b.w);
+                u32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = pack2(x[i][2 * e], x[i][2 * e + 1]);
+                *reinterpret_cast<u32x4*>(lds + (f % ROWS) * LDK + 8 * (f / ROWS)) = w;
             }
         }
     }
 };
 
 __device__ __forceinline__ bf16x8 frag(const __bf16* lds, int row, int kstep, int h) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + row * LDK + 8 * ((2 * kstep + h) ^ swz(row))));
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + row * LDK + 8 * (2 * kstep + h)));
 }
 
 // The k loop of one workgroup: acc += A[m0.., kbeg..kend) * B[kbeg..kend), n0..).
