@@ -383,8 +383,10 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
                          "traffic_profile_git_sha": (pmc_t or {}).get("_git_sha"),
                          "algorithmic_bytes_per_launch": gemm_bytes / max(1, gemm_launches),
-                         "kernel": "gemm_f32_kernel, all launches of a step (policy LSTM/vocab GEMMs fwd+bwd, "
-                                   "chain input projections and weight gradients)",
+                         "kernel": "gemm_f32_kernel, all launches of a step: the forward pass's products (the rollout's "
+                                   "vocabulary/gate products, per-word tables, chain input projections, heads) and the "
+                                   "backward pass's short ones; with --grad-products f32 also its long ones, which "
+                                   "f32x3_gemms prices otherwise",
                          "launches_per_step": gemm_launches, "gflop_per_step": gemm_flops / 1e9,
                          "ms_per_step_in_kernel": 1e3 * gemm_s,
                          "one_stream": one_stream,
