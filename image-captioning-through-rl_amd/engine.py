@@ -546,19 +546,26 @@ class A2CEngine:
         t_steps = p0 - 1 + s
         return mode != hip.GREEDY and self.vocab % 4 == 0 and s >= 4 and self.TABLE_ROWS_FACTOR * t_steps * n >= self.vocab
 
+    def _padded_vocab(self):
+        return (self.vocab + 63) // 64 * 64
+
     def _policy_table(self, ws):
         """Per-word input side of the policy LSTM, table[w] = W_ih emb[w] + b_ih + b_hh (models.py:73, 80), and
         the vocabulary projection stacked on W_hh, so that one product gives a step's logits and the recurrent
-        half of the next step's gates.  They depend on the parameters only: built beside the first rollout steps."""
+        half of the next step's gates.  They depend on the parameters only: built beside the first rollout steps.
+        The vocabulary's rows are padded with zero rows to a multiple of 64 (the gate rows are one), so that the
+        product has no ragged tile column: its workgroups take the loop with bounds checks and finish last (66 against
+        60 us per rollout step at 10 000 words)."""
         P, V = self.P, self.vocab
+        Vp = self._padded_vocab()
         if "table_p" not in ws:
             dev = self.device
             ws["table_p"] = torch.empty(V, 4 * H, dtype=torch.float32, device=dev)
-            ws["Wcat"] = torch.empty(V + 4 * H, H, dtype=torch.float32, device=dev)
-            ws["bcat"] = torch.zeros(V + 4 * H, dtype=torch.float32, device=dev)
-            ws["logits_ext"] = torch.empty(ws["logits"].shape[0], V + 4 * H, dtype=torch.float32, device=dev)
+            ws["Wcat"] = torch.zeros(Vp + 4 * H, H, dtype=torch.float32, device=dev)
+            ws["bcat"] = torch.zeros(Vp + 4 * H, dtype=torch.float32, device=dev)
+            ws["logits_ext"] = torch.empty(ws["logits"].shape[0], Vp + 4 * H, dtype=torch.float32, device=dev)
         ws["Wcat"][:V].copy_(P["linear2vocab.weight"])
-        ws["Wcat"][V:].copy_(P["lstm.weight_hh_l0"])
+        ws["Wcat"][Vp:].copy_(P["lstm.weight_hh_l0"])
         ws["bcat"][:V].copy_(P["linear2vocab.bias"])
         hip.gemm(P["caption_embedding.weight"], P["lstm.weight_ih_l0"], ws["table_p"], bias=P["lstm.bias_ih_l0"],
                  bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
@@ -601,7 +608,7 @@ class A2CEngine:
                     ev_table = True
                 ext = ws["logits_ext"][:n]
                 hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3, dtype=self.pd)
-                hip.sample_tokens_lstm_cell(ext[:, :V], mode_s, tokT[k + 1], 1, ext[:, V:], ws["table_p"], gates[k + 1],
+                hip.sample_tokens_lstm_cell(ext[:, :V], mode_s, tokT[k + 1], 1, ext[:, self._padded_vocab():], ws["table_p"], gates[k + 1],
                                             Cb[k + 1], Cb[k + 2], Hb[k + 2], **out)
                 cell_done = True
             else:
