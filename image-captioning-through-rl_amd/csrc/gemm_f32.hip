@@ -78,17 +78,21 @@ __device__ __forceinline__ void tile_load(float4 (&r)[ROWS / 32], const float* b
     }
 }
 
-// Interior tiles (all rows in range, 16-byte aligned, whole k stage in range): one pointer per
-// staged float4, set up once, no bounds logic in the k loop.
+// Interior tiles (16-byte aligned, whole k stage in range): one pointer per staged float4, set up once, no
+// bounds logic in the k loop.  A k-contiguous operand may run past its last row: the rows beyond it read the
+// last row again (their products land in output rows or columns that the epilogue does not store), so that a
+// ragged last tile row or column takes this path too instead of the loop with bounds checks, whose workgroups
+// would finish long after the others.  A row-contiguous operand must lie inside the matrix (its float4 run along
+// the rows).
 template <int ROWS, bool KM>
 __device__ __forceinline__ void tile_ptrs(const float* (&p)[ROWS / 32], const float* base, int64_t ld,
-                                          const int64_t* gather, int row0, int kbeg, int tid) {
+                                          const int64_t* gather, int row0, int nrows, int kbeg, int tid) {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
         const int f = tid + 256 * i;
         if (!KM) {
-            const int row = f >> 3, kq = f & 7;
-            const int64_t src = gather ? gather[row0 + row] : (int64_t)(row0 + row);
+            const int row = min(row0 + (f >> 3), nrows - 1), kq = f & 7;
+            const int64_t src = gather ? gather[row] : (int64_t)row;
             p[i] = base + src * ld + kbeg + 4 * kq;
         } else {
             const int k = f / (ROWS / 4), m4 = f % (ROWS / 4);
@@ -191,11 +195,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int nk = (kend - kbeg + BK - 1) / BK;
     float* const Cout = g.C + (int64_t)split * g.slab;
     const int nk_full = (kend - kbeg) / BK;  // stages that lie wholly inside the k range
-    const bool fast_a = g.a_vec && m0 + BM <= g.M, fast_b = g.b_vec && n0 + BN <= g.N;
+    const bool fast_a = g.a_vec && (!A_KM || m0 + BM <= g.M), fast_b = g.b_vec && (!B_KM || n0 + BN <= g.N);
     const float* pa[BM / 32];
     const float* pb[BN / 32];
-    if (fast_a) tile_ptrs<BM, A_KM>(pa, g.A, g.lda, g.a_rows, m0, kbeg, tid);
-    if (fast_b) tile_ptrs<BN, B_KM>(pb, g.B, g.ldb, nullptr, n0, kbeg, tid);
+    if (fast_a) tile_ptrs<BM, A_KM>(pa, g.A, g.lda, g.a_rows, m0, g.M, kbeg, tid);
+    if (fast_b) tile_ptrs<BN, B_KM>(pb, g.B, g.ldb, nullptr, n0, g.N, kbeg, tid);
     const int64_t step_a = A_KM ? (int64_t)BK * g.lda : BK, step_b = B_KM ? (int64_t)BK * g.ldb : BK;
     if (fast_a && nk_full > 0) tile_load_fast<BM>(ra, pa, 0);
     else tile_load<BM, A_KM>(ra, g.A, g.lda, g.a_rows, m0, g.M, kbeg, kend, g.a_vec, tid);
