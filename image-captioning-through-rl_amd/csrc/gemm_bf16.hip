@@ -52,8 +52,9 @@ struct Stage {
     static constexpr int PIECES = KM ? ROWS * BK / 8 / 256 : ROWS * BK / 4 / 256;
     float x[PIECES][KM ? 8 : 4];
 
-    // EDGE = false: the tile lies inside the matrix, rows are not gathered and every float4 is aligned: plain
-    // loads, no branches (so that the compiler can keep several stages' loads outstanding).
+    // EDGE = false: whole k stages, rows not gathered, every float4 aligned: plain loads, no branches (so that the
+    // compiler can keep several stages' loads outstanding).  Rows past the matrix' last one read the last row again
+    // (the epilogue does not store their products): a ragged last tile row or column stays on this path.
     template <bool EDGE>
     __device__ __forceinline__ void load(const float* base, int64_t ld, const int64_t* gather, int row0, int nrows,
                                          int k0, int kend, int tid) {
@@ -61,7 +62,7 @@ struct Stage {
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + 256 * i;
             if (!KM) {
-                const int gr = row0 + (f >> 4), gk = k0 + 4 * (f & 15);
+                const int gr = EDGE ? row0 + (f >> 4) : min(row0 + (f >> 4), nrows - 1), gk = k0 + 4 * (f & 15);
                 if (!EDGE) {
                     const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)gr * ld + gk);
                     x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
@@ -72,7 +73,7 @@ struct Stage {
                     for (int e = 0; e < 4; ++e) x[i][e] = (gr < nrows && gk + e < kend) ? p[e] : 0.f;
                 }
             } else {
-                const int gr = row0 + f % ROWS, gk = k0 + 8 * (f / ROWS);
+                const int gr = EDGE ? row0 + f % ROWS : min(row0 + f % ROWS, nrows - 1), gk = k0 + 8 * (f / ROWS);
                 const float* p = base + (int64_t)gk * ld + gr;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[i][e] = (!EDGE || (gr < nrows && gk + e < kend)) ? p[e * ld] : 0.f;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                          g.lda % 4 == 0 && g.ldb % 4 == 0 && kbeg % 4 == 0;
     // a tile inside the matrix walks its full stages on the branch-free path; a last, partial stage (k not a
     // multiple of BK) and the tiles on the matrix' edges take the bounds-checked one
-    const bool interior = aligned && !g.a_rows && m0 + BM <= g.M && n0 + BN <= g.N;
+    const bool interior = aligned && !g.a_rows;   // (ragged tile rows and columns included: Stage::load)
     const int full = (kend - kbeg) / BK;
     if (interior && full > 0) {
         k_loop<BM, BN, A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);

@@ -61,14 +61,16 @@ struct Stage {
     static_assert(PIECES >= 1 && PIECES * NT * (KM ? 8 : 4) == ROWS * BK, "the tile divides among the threads");
     float x[PIECES][KM ? 8 : 4];
 
-    // EDGE = false: the tile lies inside the matrix and (KM = false) every float4 is aligned: plain loads, no branches.
+    // EDGE = false: whole k stages and (KM = false) aligned float4: plain loads, no branches.  Rows past the matrix'
+    // last one read the last row again (the epilogue does not store their products), so that a ragged last tile row
+    // or column does not fall to the bounds-checked loads, whose workgroups would finish long after the others.
     template <bool EDGE>
     __device__ __forceinline__ void load(const float* base, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + NT * i;
             if (!KM) {
-                const int gr = row0 + f / (BK / 4), gk = k0 + 4 * (f % (BK / 4));
+                const int gr = EDGE ? row0 + f / (BK / 4) : min(row0 + f / (BK / 4), nrows - 1), gk = k0 + 4 * (f % (BK / 4));
                 const float* p = base + (int64_t)gr * ld + gk;
                 if (!EDGE) {
                     const float4 v = *reinterpret_cast<const float4*>(p);
@@ -78,7 +80,7 @@ struct Stage {
                     for (int e = 0; e < 4; ++e) x[i][e] = (gr < nrows && gk + e < kend) ? p[e] : 0.f;
                 }
             } else {
-                const int gr = row0 + f % ROWS, gk = k0 + 8 * (f / ROWS);
+                const int gr = EDGE ? row0 + f % ROWS : min(row0 + f % ROWS, nrows - 1), gk = k0 + 8 * (f / ROWS);
                 const float* p = base + (int64_t)gk * ld + gr;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[i][e] = (!EDGE || (gr < nrows && gk + e < kend)) ? p[e * ld] : 0.f;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
 
     const bool aligned = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(g.B) % 16 == 0) &&
                          g.lda % 4 == 0 && g.ldb % 4 == 0 && kbeg % 4 == 0;
-    const bool interior = aligned && m0 + BM <= g.M && n0 + BN <= g.N;
+    const bool interior = aligned;   // (ragged tile rows and columns included: Stage::load)
     const int full = (kend - kbeg) / BK;
     if (interior && full > 0) {
         k_loop<A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
