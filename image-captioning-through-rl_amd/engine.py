@@ -384,7 +384,7 @@ class A2CEngine:
         plans = [("segmented", k, w) for w in self.warmups] if k else []
         return plans + [("exact",)]
 
-    WARM16_MIN_WARMUP = 128   # shorter warm-ups gain nothing: the extra launch costs what its steps save
+    WARM16_MIN_WARMUP = 96   # shorter warm-ups gain nothing: the extra launch costs what its steps save (at 96: 7.13-7.29 against 7.37-7.42 ms per step)
     WARM16_TAIL = 16   # float32 steps that end a warm-up whose first part ran at 16-bit precision (at least W / 8)
 
     @staticmethod
