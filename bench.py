@@ -14,9 +14,12 @@ Beside the K timed steps the line carries
   * `soak`: a further run of minibatches on the same networks (they keep training, and the value LSTM's
     memory - hence the chains' warm-up - grows with it): mean / p95 step time, the plans it ended on and
     how many minibatches had to be redone;
-  * `roofline`: the f32 MFMA GEMM launches of one timed step (HIP events around every launch, on the stream
-    it is launched on), FLOPs / time against the f32 MFMA peak; `roofline.one_stream`: the same launches of one
-    more minibatch run on ONE stream, with nothing beside them;
+  * `roofline`: the step's dominant kernel - gemm_f32x3_kernel, the backward pass's products over all positions -
+    from HIP events around every one of its launches in one timed step (on the stream it is launched on): element
+    products / time against the f32 MFMA peak, the issued bf16 piece products against the bf16 peak beside it;
+    `roofline.one_stream`: the same launches of one more minibatch run on ONE stream, with nothing beside them;
+    `roofline_f32_gemm`: the same for the gemm_f32_kernel launches; `roofline_all_gemms`: every GEMM launch;
+  * `steady_state`: the soak's mean as images/s, beside `value`;
   * `chains`: the recurrent-chain launches of the same step with the steps they walked, their MFMA work as
     executed (warm-up included) and as the reference's chains would need;
   * `cpu_baseline`: the reference-shaped float32 CPU port timed on this host (rank 0, N = 1 only).
@@ -56,6 +59,47 @@ def build_networks(syn, models, optim, vocab, fdim, seed, dev, value_forget_bias
     a2c = models.AdvantageActorCriticNetwork(val, pol).to(dev)
     flat = optim.flatten_module(a2c)
     return a2c, rew, flat, params
+
+
+def pretrained_networks(syn, models, optim, trainers, vocab, fdim, n, minibatches, dev):
+    """The three networks as the reference's pipeline hands them to the A2C loop (trainers.py:331-370): each trained
+    by its own pre-training loop (train_reward_network, train_policy_network, train_value_network) for `minibatches`
+    minibatches of n rows on a synthetic ragged-caption set of 4 n rows, then loaded from the checkpoints those
+    loops wrote (their best-loss states, as the reference loads them)."""
+    import math
+    import tempfile
+    torch.manual_seed(0)
+    np.random.seed(0)
+    import random
+    random.seed(0)
+    data = syn.make_ragged_train_data(4 * n, vocab, fdim, 0)
+    epochs = max(1, math.ceil(minibatches / 4))
+    tmp = tempfile.mkdtemp(prefix="icrl_pretrain_")
+    paths = {k: os.path.join(tmp, k + ".pt") for k in ("reward_network", "policy_network", "value_network")}
+    log = trainers.ScalarLog()
+    t0 = time.perf_counter()
+    trainers.train_reward_network(data, paths, log, False, epochs=epochs, batch_size=n)
+    trainers.train_policy_network(data, paths, log, False, epochs=epochs, batch_size=n)
+    trainers.train_value_network(data, paths, log, False, epochs=epochs, batch_size=n)
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    w2i = data["word_to_idx"]
+    nets = {"policy_network": models.PolicyNetwork(w2i, input_dim=fdim),
+            "value_network": models.ValueNetwork(w2i, feature_dim=fdim),
+            "reward_network": models.RewardNetwork(w2i, feature_dim=fdim)}
+    for k, net in nets.items():
+        net.load_state_dict(torch.load(paths[k], map_location="cpu", weights_only=True), strict=False)
+        net.to(dev)
+        os.remove(paths[k])
+    os.rmdir(tmp)
+    nets["reward_network"].requires_grad_(False)
+    a2c = models.AdvantageActorCriticNetwork(nets["value_network"], nets["policy_network"]).to(dev)
+    losses = {}
+    for tag, value, _ in log.records:
+        losses.setdefault(tag, []).append(value)
+    info = {"minibatches_per_network": 4 * epochs, "rows_per_minibatch": n, "seconds": secs,
+            "losses_first_last_best": {t: [v[0], v[-1], min(v)] for t, v in losses.items()}}
+    return a2c, nets["reward_network"], optim.flatten_module(a2c), info
 
 
 def host_cores():
@@ -153,6 +197,9 @@ def main():
     ap.add_argument("--chain-semantics", default="batch", choices=("batch", "per_sample"),
                     help="per_sample: every image owns its value / reward recurrent state (NOT the headline "
                          "workload: a different computation, reported under its own workload name)")
+    ap.add_argument("--pretrain", type=int, default=0,
+                    help="run each of the three pre-training loops for this many minibatches first and bench the A2C "
+                         "step on the networks they produce (trained-regime run, reported under its own workload name)")
     ap.add_argument("--no-collapse", action="store_true", help="walk every call of the chains in full")
     ap.add_argument("--no-warm16", action="store_true", help="every warm-up step on the float32 matrix instruction")
     args = ap.parse_args()
@@ -177,6 +224,11 @@ def main():
     steps_per_rollout = caplen - 1
 
     a2c, rew, flat, params = build_networks(syn, models, optim, vocab, fdim, 0, dev, args.value_forget_bias)
+    pretrain_info = None
+    if args.pretrain > 0:
+        assert world == 1 and not args.value_forget_bias, "--pretrain: one GPU, no forget-bias shift"
+        a2c, rew, flat, pretrain_info = pretrained_networks(syn, models, optim, trainers, vocab, fdim, n,
+                                                            args.pretrain, dev)
     opt = optim.FusedAdam(flat, lr=1e-4)
     engine_opts = dict(chain_semantics=args.chain_semantics, collapse_replays=not args.no_collapse)
     if args.no_warm16:
@@ -313,11 +365,52 @@ def main():
     peak = F32_MFMA_PEAK_TFLOPS
     achieved = gemm_flops / gemm_s / 1e12
     pmc_t, pmc_m = load_profile("pmc_traffic.json"), load_profile("pmc_mfma.json")
-    traffic = None
-    if pmc_t and "gemm_f32_kernel" in pmc_t:
-        traffic = pmc_t["gemm_f32_kernel"]["fetch_bytes_per_launch"] + pmc_t["gemm_f32_kernel"]["write_bytes_per_launch"]
+
+    def pmc_traffic(kernel):
+        if pmc_t and kernel in pmc_t:
+            return pmc_t[kernel]["fetch_bytes_per_launch"] + pmc_t[kernel]["write_bytes_per_launch"]
+        return None
+    traffic = pmc_traffic("gemm_f32_kernel")
     mfma_util = {k: v["mfma_utilisation"] for k, v in pmc_m.items() if isinstance(v, dict) and "mfma_utilisation" in v} \
         if pmc_m else None
+    common = {"traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
+              "traffic_profile_git_sha": (pmc_t or {}).get("_git_sha"),
+              "events": "HIP events around every launch of the first of the timed steps, on its own stream",
+              "mfma_utilisation_pmc": mfma_util, "mfma_profile_git_sha": (pmc_m or {}).get("_git_sha"),
+              "mfma_utilisation_note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch cycles * 1024 SIMDs) per kernel, "
+                                       "kernels run one at a time (profiles/pmc_mfma.json)"}
+    roofline_f32 = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": gemm_bytes / max(1, gemm_launches),
+                    "kernel": "gemm_f32_kernel, all launches of a step: the forward pass's products (the rollout's "
+                              "vocabulary/gate products, per-word tables, chain input projections, heads) and the "
+                              "backward pass's short ones; with --grad-products f32 also its long ones",
+                    "launches_per_step": gemm_launches, "gflop_per_step": gemm_flops / 1e9,
+                    "ms_per_step_in_kernel": 1e3 * gemm_s, "one_stream": one_stream}
+    # the step's dominant kernel is the one `roofline` prices: the three-piece products when the backward pass runs
+    # on them (they hold most of the step's GEMM work and in-kernel time), the exact-f32 kernel otherwise
+    if x3 is not None and x3["ms_per_step_in_kernel"] >= 1e3 * gemm_s * 0.5:
+        roofline = {"bound": "mfma", "achieved": x3["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
+                    "frac": x3["frac_of_f32_mfma_peak"], "traffic": pmc_traffic("gemm_f32x3_kernel"),
+                    "algorithmic_bytes_per_launch": x3["algorithmic_bytes_per_launch"],
+                    "kernel": x3["kernel"], "launches_per_step": x3["launches_per_step"],
+                    "gflop_per_step": x3["gflop_per_step"], "ms_per_step_in_kernel": x3["ms_per_step_in_kernel"],
+                    "peak_note": "achieved / peak count ELEMENT products (2 M N K) against the f32 MFMA peak, the "
+                                 "rate an exact-f32 kernel could reach at best; the kernel issues six bf16 piece "
+                                 "products per element product, priced against the bf16 MFMA peak beside it",
+                    "bf16_mfma_tflops_issued": x3["bf16_mfma_tflops_issued"], "peak_bf16_mfma": BF16_MFMA_PEAK_TFLOPS,
+                    "frac_of_bf16_mfma_peak": x3["frac_of_bf16_mfma_peak"], "one_stream": x3_alone}
+    else:
+        roofline = dict(roofline_f32)
+    roofline.update(common)
+    all_fl = sum(a[0] for k, a in acc.items() if k.startswith("gemm"))
+    all_s = sum(a[1] for k, a in acc.items() if k.startswith("gemm"))
+    roofline_all = None if all_s <= 0 else {
+        "kernels": sorted(k for k in acc if k.startswith("gemm")),
+        "launches_per_step": sum(a[2] for k, a in acc.items() if k.startswith("gemm")), "gflop_per_step": all_fl / 1e9,
+        "ms_per_step_in_kernel": 1e3 * all_s, "achieved": all_fl / all_s / 1e12, "unit": "TFLOP/s",
+        "frac_of_f32_mfma_peak": all_fl / all_s / 1e12 / peak,
+        "note": "every GEMM launch of the profiled step, element products over the sum of the launches' durations "
+                "(they overlap each other and the chains, so the durations add up to more than the step)"}
 
     # the chains: steps each launch walked, MFMA work executed and the work the reference's chains hold
     gates = {"lstm_chain_fwd": 4, "gru_chain_fwd": 3, "lstm_chain_bwd": 4}
@@ -360,6 +453,10 @@ def main():
             variant.append("NOT the metric's workload: per-image recurrent state")
         if args.value_forget_bias:
             variant.append("NOT the metric's workload: value LSTM forget bias +%g (long-memory stress case)" % args.value_forget_bias)
+        if pretrain_info:
+            variant.append("networks pre-trained for %d minibatches each by the three pre-training loops: a "
+                           "trained-regime run, not the headline's fresh initialisation"
+                           % pretrain_info["minibatches_per_network"])
         if args.policy_dtype != "f32":
             variant.append("NOT the metric's arithmetic: policy network products in %s" % args.policy_dtype)
         if (n, fdim, vocab, caplen) != (512, 2048, 10000, 20):
@@ -378,23 +475,14 @@ def main():
             "parameters_identical_across_ranks": in_step if world > 1 else None,
             "launches_that_gave_up_waiting": gave_up,
             "soak": soak,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC, profiles/pmc_traffic.json)",
-                         "traffic_profile_git_sha": (pmc_t or {}).get("_git_sha"),
-                         "algorithmic_bytes_per_launch": gemm_bytes / max(1, gemm_launches),
-                         "kernel": "gemm_f32_kernel, all launches of a step: the forward pass's products (the rollout's "
-                                   "vocabulary/gate products, per-word tables, chain input projections, heads) and the "
-                                   "backward pass's short ones; with --grad-products f32 also its long ones, which "
-                                   "f32x3_gemms prices otherwise",
-                         "launches_per_step": gemm_launches, "gflop_per_step": gemm_flops / 1e9,
-                         "ms_per_step_in_kernel": 1e3 * gemm_s,
-                         "one_stream": one_stream,
-                         "events": "HIP events around every launch of the first of the timed steps, on its own stream",
-                         "mfma_utilisation_pmc": mfma_util,
-                         "mfma_profile_git_sha": (pmc_m or {}).get("_git_sha"),
-                         "mfma_utilisation_note": "SQ_VALU_MFMA_BUSY_CYCLES / (dispatch cycles * 1024 SIMDs) per kernel, "
-                                                  "kernels run one at a time (profiles/pmc_mfma.json)"},
+            "pretrain": pretrain_info,
+            "steady_state": None if soak is None else {
+                "value": soak["images_per_s"], "unit": "images/s", "ms_per_step": soak["ms_per_step_mean"],
+                "note": "mean over the soak's %d further minibatches of the same networks (see `soak`); `value` above "
+                        "is the state after %d minibatches" % (args.soak, args.warmup)},
+            "roofline": roofline,
+            "roofline_f32_gemm": roofline_f32,
+            "roofline_all_gemms": roofline_all,
             "bf16_gemms": bf16,
             "f32x3_gemms": x3,
             "grad_products": engine.vgd,
@@ -414,7 +502,8 @@ def main():
             "chain_plan": final_plans, "seam_check": engine.last_seam,
             "seam_fallbacks_in_run": timed_fallbacks, "last_loss": last_loss, "git_sha": git_sha(),
         }
-        if world == 1 and not args.no_cpu_baseline and args.chain_semantics == "batch" and not args.value_forget_bias:
+        if (world == 1 and not args.no_cpu_baseline and args.chain_semantics == "batch" and not args.value_forget_bias
+                and not pretrain_info):
             out["cpu_baseline"] = cpu_baseline(syn, params, vocab, caplen, fdim, args.cpu_sample_batch, args.cpu_repeats)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
             if soak:

@@ -23,6 +23,7 @@
 //              waves split the 2048 gate rows (k), their partial tiles are summed in LDS,
 //              the cell's backward runs in the epilogue and writes the next step's dgates.
 #include <algorithm>
+#include <atomic>
 
 #include "chain_seg_common.h"
 
@@ -1887,7 +1888,9 @@ int lstm_fwd_seg_on(const char* who, const float* xproj, const float* w_hh, int 
 constexpr int STATIC_MAX_SEGMENTS = 128;
 constexpr int STATIC_MAX_DEVICES = 64;
 static __device__ __align__(256) float scratch[(size_t)STATIC_MAX_SEGMENTS * 16 * H];
-float* scratch_of_device[STATIC_MAX_DEVICES];   // zero-initialised; set once per device, that device current
+// zero-initialised; set on the first call on a device, that device current.  Two host threads that make their
+// first calls together both look the same address up and both store it: atomic, so neither reads a torn pointer
+std::atomic<float*> scratch_of_device[STATIC_MAX_DEVICES];
 }  // namespace
 
 extern "C" int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,
@@ -1906,14 +1909,23 @@ extern "C" int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w
     int dev = -1;
     ICRL_HIP(hipGetDevice(&dev));
     ICRL_REQUIRE(dev >= 0 && dev < STATIC_MAX_DEVICES, "icrl_lstm_chain_fwd_seg_static: device %d not supported", dev);
-    if (scratch_of_device[dev] == nullptr) {   // first call on this device (it is the current one)
-        float* ptr = nullptr;
+    // every GPU holds its own copy of the array: the one used is the current device's, so the stream must
+    // belong to it (a stream of another GPU would be handed an address of the wrong GPU's memory)
+    hipStream_t st = icrl::as_stream(stream);
+    if (st != nullptr) {
+        hipDevice_t sdev = -1;
+        ICRL_HIP(hipStreamGetDevice(st, &sdev));
+        ICRL_REQUIRE((int)sdev == dev, "icrl_lstm_chain_fwd_seg_static: the stream belongs to device %d, the current "
+                     "device is %d; make the stream's device current before the call", (int)sdev, dev);
+    }
+    float* ptr = scratch_of_device[dev].load(std::memory_order_acquire);
+    if (ptr == nullptr) {   // first call on this device (it is the current one)
         ICRL_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
         ICRL_REQUIRE(ptr != nullptr, "icrl_lstm_chain_fwd_seg_static: no address for the static workspace");
-        scratch_of_device[dev] = ptr;
+        scratch_of_device[dev].store(ptr, std::memory_order_release);
     }
     return lstm_fwd_seg_on("icrl_lstm_chain_fwd_seg_static", xproj, w_hh, N, p0, n_calls, full_calls, segments, warmup,
-                           h_emit, saved, state_in, scratch_of_device[dev], seam_err, icrl::as_stream(stream));
+                           h_emit, saved, state_in, ptr, seam_err, st);
 }
 
 extern "C" int icrl_gru_chain_fwd_seg(const float* xproj, const float* w_hh, const float* b_hh, int N, int p0,

@@ -321,10 +321,6 @@ class A2CEngine:
                 dY=f32(s * n, 512), dYsum=f32(n, 512), gw1h=f32(512, H), d_emit=f32(s, n, H),
                 dGsum=f32(lv * n, 4 * H), dXv=f32(lv * n, ev))
         if self.R is not None:
-            if s > 1:   # the A2C step's per-word input projections (see _word_tables)
-                ws["table_r"] = f32(self.R["rewrnn.caption_embedding.weight"].shape[0], 3 * H)
-                if self.V is not None:
-                    ws["table_v"] = f32(self.V["valrnn.caption_embedding.weight"].shape[0], 4 * H)
             ws.update(
                 XPr=f32(l_cols * n, 3 * H), hr=f32(s, n, H), se=f32(s * n, 512), ve=f32(n, 512), rewards=f32(s * n),
                 sync_r=torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device=dev))
@@ -644,6 +640,10 @@ class A2CEngine:
         n, l_cols = captions.shape
         s = l_cols - 1
         ws = self._buffers(n, 1, s)
+        # an A2C step on the same shape shares this workspace: none of its pending work belongs to this pass
+        ws["policy_early"] = False
+        ws.pop("early_pending", None)
+        ws.pop("head_grads_pending", None)
         ws["tokT"].copy_(captions.t())
         self._rollout(ws, features, n, 1, s, None, hip.FORCED)
         self._order_tokens(ws, n, s * n, torch.cuda.current_stream(), torch.cuda.current_stream())
@@ -884,7 +884,12 @@ class A2CEngine:
         # stands while the device is still busy with the backward pass.  A rejected forward seam or replay
         # check redoes everything after the rollout; a rejected backward seam only the value chain's BPTT,
         # unless its longer warm-up also asks for more calls in full.
+        ev_replay = None
         while True:
+            if ev_replay is not None:
+                # a rejected attempt's replay check may still be reading the chains' buffers on its own stream:
+                # nothing of the next attempt (which rewrites and may reallocate them) is queued in front of it
+                main.wait_event(ev_replay)
             fc, pv, pr, pb = self._choose(ws, n, p0, s, fv, fr, bi)
             if pv[0] == "exact":
                 bi = last
@@ -989,6 +994,11 @@ class A2CEngine:
         rollout; once the tokens exist a position's projection is a row gather - row by row the same sums as
         the product over the gathered embeddings."""
         V, R = self.V, self.R
+        if "table_v" not in ws:   # allocated by the first A2C step of the shape (the pre-training steps need none)
+            ws["table_r"] = torch.empty(R["rewrnn.caption_embedding.weight"].shape[0], 3 * H, dtype=torch.float32,
+                                        device=self.device)
+            ws["table_v"] = torch.empty(V["valrnn.caption_embedding.weight"].shape[0], 4 * H, dtype=torch.float32,
+                                        device=self.device)
         hip.gemm(V["valrnn.caption_embedding.weight"], V["valrnn.lstm.weight_ih_l0"], ws["table_v"],
                  bias=V["valrnn.lstm.bias_ih_l0"], bias2=V["valrnn.lstm.bias_hh_l0"])
         # a reward network declared frozen (it is, during A2C training: trainers.py:372-373) keeps its table
@@ -1213,6 +1223,9 @@ class A2CEngine:
         late = self.concurrent
         self._value_head_backward(ws, features, n, s, weights=not late)
         ws["head_grads_pending"] = (features, n, s) if late else None
+        if late:   # whoever forms the head's weight gradients on another stream reads dY: after this point
+            ws["ev_head_dY"] = torch.cuda.Event()
+            ws["ev_head_dY"].record(main)
         self._value_chain_backward(ws, n, p0, s, fc, main, side, plan, ev_loss, features)
         ev_head = ws.pop("ev_head_grads", None)
         if ev_head is not None:
@@ -1366,6 +1379,7 @@ class A2CEngine:
             ev_vocab.record(other)
             pending = ws.pop("head_grads_pending", None) if other is not cur else None
             if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
+                other.wait_event(ws["ev_head_dY"])
                 self._value_head_weight_grads(ws, *pending, sc, cs)
                 ws["ev_head_grads"] = torch.cuda.Event()
                 ws["ev_head_grads"].record(other)

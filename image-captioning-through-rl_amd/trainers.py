@@ -496,7 +496,7 @@ def train_a2c_network(train_data, save_paths, network_paths, plot_dir, bidirecti
                                    batch_size, epochs, chain_semantics=chain_semantics, policy_dtype=policy_dtype)
     else:
         if 16 not in curriculum:
-            curriculum.append(16)  # Final Curriculum Level, ie Full Training
+            curriculum.append(16)  # a curriculum always ends with the whole 16-step rollout (trainers.py:389-390)
         a2c_network = a2c_curriculum_training(train_data, a2c_network, reward_network, optimizer, plot_dir,
                                               save_paths, batch_size, epochs, curriculum,
                                               chain_semantics=chain_semantics, policy_dtype=policy_dtype)

@@ -294,7 +294,9 @@ int icrl_lstm_chain_fwd_seg(const float* xproj, const float* w_hh, int N, int p0
  * Same arguments minus `work`, same kernels and the same results bit for bit; the segment workspace is a
  * static device array inside the library (4 MiB per GPU, held until the process ends), so segments is
  * limited to 128 and larger values are rejected with ICRL_ERR_ARG.  The call makes no hipMalloc / hipFree
- * (its first call on a device looks the array's address up once).  Every call on one GPU shares that
+ * (its first call on a device looks the array's address up once, which may load the code object: make one
+ * call on each device before starting a stream capture there).  The array used is the CURRENT device's, and
+ * `stream` must belong to that device (ICRL_ERR_ARG otherwise).  Every call on one GPU shares that
  * array: calls that overlap on one GPU (two streams, two host threads) race; calls in stream order are
  * safe, whatever their sizes. */
 int icrl_lstm_chain_fwd_seg_static(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,

@@ -66,8 +66,14 @@ def cdf_edge_distance(p_row, u):
     return float(np.min(np.abs(cdf - u)))
 
 
-def _lstm_step(xp, h, c, whh_t):
-    g = xp + h @ whh_t
+def _rounded(x, operand_dtype):
+    """x with every element rounded to operand_dtype (round to nearest even) and widened again: the value a
+    matrix unit multiplies when its operands are stored in that type and its sums are kept wide."""
+    return x if operand_dtype is None else x.to(operand_dtype).to(x.dtype)
+
+
+def _lstm_step(xp, h, c, whh_t, operand_dtype=None):
+    g = xp + _rounded(h, operand_dtype) @ whh_t
     i, f, gg, o = g.split(g.shape[-1] // 4, dim=-1)
     c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
     h = torch.sigmoid(o) * torch.tanh(c)
@@ -84,8 +90,13 @@ def _gru_step(xp, h, whh_t, bhh):
     return (1.0 - z) * n + z * h
 
 
-def policy_rollout(P, features, prefix, n_steps, uniforms=None, mode="sample", forced=None):
+def policy_rollout(P, features, prefix, n_steps, uniforms=None, mode="sample", forced=None, operand_dtype=None):
     """Incremental policy rollout.
+
+    operand_dtype (e.g. torch.bfloat16): both operands of every product of the policy network
+    (models.py:75, 80, 82) are rounded to that type before they are multiplied; sums, biases, the cell
+    and the softmax stay in the parameters' dtype.  With float64 parameters this is the exact result
+    of reduced-precision operands with wide accumulation, the arithmetic of the opt-in bf16 mode.
 
     prefix: int64 [N, p0] ground-truth start columns (p0 = 1 for plain A2C).
     mode: "sample" (inverse CDF with uniforms[n_steps, N]), "greedy" (argmax on the
@@ -94,21 +105,23 @@ def policy_rollout(P, features, prefix, n_steps, uniforms=None, mode="sample", f
     Returns tokens [N, p0+n_steps], logits [n_steps, N, V], log_probs [N, n_steps].
     """
     n, p0 = prefix.shape
-    emb = P["caption_embedding.weight"]
-    wih_t = P["lstm.weight_ih_l0"].t()
-    whh_t = P["lstm.weight_hh_l0"].t()
+    od = operand_dtype
+    emb = _rounded(P["caption_embedding.weight"], od)
+    wih_t = _rounded(P["lstm.weight_ih_l0"], od).t()
+    whh_t = _rounded(P["lstm.weight_hh_l0"], od).t()
+    wvocab_t = _rounded(P["linear2vocab.weight"], od).t()
     bias = P["lstm.bias_ih_l0"] + P["lstm.bias_hh_l0"]
     feats = torch.as_tensor(features, dtype=emb.dtype)
-    h = feats @ P["cnn2linear.weight"].t() + P["cnn2linear.bias"]
+    h = _rounded(feats, od) @ _rounded(P["cnn2linear.weight"], od).t() + P["cnn2linear.bias"]
     c = torch.zeros_like(h)
     tokens = torch.as_tensor(np.asarray(prefix), dtype=torch.int64).clone()
     for t in range(p0 - 1):  # prime on the ground-truth prefix, no outputs needed
-        h, c = _lstm_step(emb[tokens[:, t]] @ wih_t + bias, h, c, whh_t)
+        h, c = _lstm_step(emb[tokens[:, t]] @ wih_t + bias, h, c, whh_t, od)
     all_logits, log_probs = [], []
     for k in range(n_steps):
         col = p0 - 1 + k
-        h, c = _lstm_step(emb[tokens[:, col]] @ wih_t + bias, h, c, whh_t)
-        logits = h @ P["linear2vocab.weight"].t() + P["linear2vocab.bias"]
+        h, c = _lstm_step(emb[tokens[:, col]] @ wih_t + bias, h, c, whh_t, od)
+        logits = _rounded(h, od) @ wvocab_t + P["linear2vocab.bias"]
         all_logits.append(logits)
         if mode == "greedy":
             act = logits.detach().argmax(dim=1)

@@ -656,3 +656,35 @@ def test_lookahead_decoder_joined_value_chains_segment_parallel_equal_the_exact_
     for (tok_s, score_s), (tok_e, score_e) in zip(out["segmented"], out["exact"]):
         assert torch.equal(tok_s, tok_e)
         np.testing.assert_allclose(score_s.cpu().numpy(), score_e.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_one_step_rollout_matches_oracle():
+    """A rollout of a single step (curriculum level 1, trainers.py:547-594): every output and gradient against the
+    float64 oracle, sampled and teacher-forced."""
+    cfg = dict(n=6, vocab=100, caplen=10, fdim=512, seed=4, level=1)
+    a2c, rew = build_modules(cfg)
+    feats, caps = synthetic.make_minibatch(cfg["n"], cfg["vocab"], cfg["caplen"], cfg["fdim"], cfg["seed"])
+    u = synthetic.make_uniforms(cfg["seed"], cfg["n"])
+    p0 = cfg["caplen"] - 1
+    res = run_step(a2c, rew, feats, caps, p0, 1, uniforms=torch.from_numpy(u).cuda())
+    toks = res.tokens.cpu().numpy()
+    want = orc.a2c_step(*params_for(cfg), feats, caps, uniforms=u, level=1)
+    assert np.array_equal(toks, want["tokens"])
+    np.testing.assert_allclose(res.log_probs.cpu().numpy(), want["log_probs"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.values.cpu().numpy(), want["values"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res.rewards.cpu().numpy(), want["rewards"], rtol=RTOL, atol=ATOL)
+    assert abs(float(res.scalars[0]) - want["loss"]) <= RTOL * abs(want["loss"]) + 2e-6
+    for prefix, grads in (("policy_network.", want["policy_grads"]), ("value_network.", want["value_grads"])):
+        for k, g in grads.items():
+            got = dict(a2c.named_parameters())[prefix + k].grad.cpu().numpy()
+            scale = np.sqrt((g * g).mean())
+            np.testing.assert_allclose(got, g, rtol=2e-3, atol=2e-3 * scale + 1e-7, err_msg=k)
+    # and from the first column: p0 = 1, one step
+    res1 = run_step(a2c, rew, feats, caps, 1, 1, uniforms=torch.from_numpy(u).cuda())
+    caps1 = caps.copy()
+    caps1[:, 1] = 2   # an <END> in column 1 makes the oracle's caption length 2: one step from the <START> column
+    caps1[:, 2:] = 0
+    want1 = orc.a2c_step(*params_for(cfg), feats, caps1, uniforms=u, want_grads=False)
+    assert want1["n_steps"] == 1 and np.array_equal(res1.tokens.cpu().numpy(), want1["tokens"])
+    np.testing.assert_allclose(res1.values.cpu().numpy(), want1["values"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res1.rewards.cpu().numpy(), want1["rewards"], rtol=RTOL, atol=ATOL)

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from helpers import params_for, synthetic
+from oracle import a2c_oracle as orc
 from oracle import cpu_port
 
 pytestmark = pytest.mark.gpu
@@ -92,3 +93,45 @@ def test_bf16_policy_arithmetic_against_the_float32_step_on_the_same_tokens(batc
     toks = free.tokens.cpu().numpy()
     assert toks.min() >= 0 and toks.max() < CFG["vocab"] and np.isfinite(free.log_probs.cpu().numpy()).all()
     assert (toks == f32.tokens.cpu().numpy()).mean() > 0.9    # most draws are far from a CDF edge
+
+
+def test_bf16_policy_arithmetic_against_the_operand_rounding_oracle(batch64):
+    """The bf16 step's log-probabilities against the float64 oracle with both operands of every policy product
+    (models.py:75-82) rounded to bf16 and wide sums: the arithmetic the mode claims, not merely "near float32".
+    Teacher-forced on the float32 step's tokens.  Tolerance: rtol 1e-3 of the log-probability is the stated bar;
+    what is measured is far inside it (float32 against float64 sums, and a rare element of h that the two round
+    to different bf16 neighbours), and several times closer than the unrounded oracle is."""
+    b = batch64
+    tokens = b["res"].tokens
+    engine = trainers.build_engine(b["a2c"], b["rew"], policy_dtype="bf16")
+    res = engine.step(torch.from_numpy(b["feats"]).cuda(), torch.from_numpy(b["caps"][:, :1]).cuda(), STEPS,
+                      mode=hip.FORCED, forced_tokens=tokens, backward=False).check()
+    got = res.log_probs.cpu().numpy().astype(np.float64)
+    P = orc.to_t(params_for(CFG)[0])
+    forced = tokens.cpu().numpy()[:, 1:]
+    with torch.no_grad():
+        _, _, want = orc.policy_rollout(P, b["feats"], b["caps"][:, :1], STEPS, mode="forced", forced=forced,
+                                        operand_dtype=torch.bfloat16)
+        _, _, exact = orc.policy_rollout(P, b["feats"], b["caps"][:, :1], STEPS, mode="forced", forced=forced)
+    want, exact = want.numpy(), exact.numpy()
+    err_model, err_exact = np.abs(got - want).max(), np.abs(got - exact).max()
+    print("bf16 step log-probs: max |diff| %.3g against the bf16-rounding oracle, %.3g against the unrounded one"
+          % (err_model, err_exact))
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=0)
+    assert err_model <= 2e-4, "further from the operand-rounding model than float32 sums explain"
+    assert err_model < 0.25 * err_exact, "no closer to the bf16 model than to exact arithmetic"
+
+
+def test_greedy_ids_at_vocabulary_10k_against_the_float64_oracle(batch64):
+    """GenerateCaptionsGreedy (trainers.py:57-70) at the batch-64 configuration's size: ids equal to the float64
+    oracle's wherever the oracle's top-2 logit margin exceeds 1e-5 (below it the arg-max is not well posed)."""
+    b = batch64
+    want, margins = orc.greedy_decode(params_for(CFG)[0], b["feats"], b["caps"])
+    got = trainers.GenerateCaptionsGreedy(b["feats"], b["caps"], b["a2c"].policy_network).cpu().numpy()
+    assert got.dtype == np.int64 and got.shape == want.shape == (CFG["n"], 17)
+    fragile = margins < 1e-5
+    first = np.where(fragile.any(axis=1), fragile.argmax(axis=1), 16)   # first step whose arg-max is not well posed
+    print("rows with a top-2 margin under 1e-5: %d of %d (smallest margin %.3g)" % (fragile.any(axis=1).sum(), CFG["n"], margins.min()))
+    for i in range(CFG["n"]):
+        assert np.array_equal(got[i, :first[i] + 1], want[i, :first[i] + 1]), i
+    assert fragile.any(axis=1).mean() <= 0.05

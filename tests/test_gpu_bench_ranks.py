@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 _launches = []
 
 
-def _launch(ranks, extra, timeout=240):
+def _launch(ranks, extra, timeout=240, backend="gloo", env_extra=None):
     _launches.append(1)
     port = 29700 + (os.getpid() * 7 + len(_launches) * 13) % 250   # a fresh port per launch
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(ranks), "--backend", "gloo", "--no-cpu-baseline"] + extra
+           "--gpus", str(ranks), "--backend", backend, "--no-cpu-baseline"] + extra
     # a rank still running after 120 s prints its threads' stacks and exits, so a hang names its place
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICRL_BENCH_WATCHDOG="120")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICRL_BENCH_WATCHDOG="120", **(env_extra or {}))
     done = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert done.returncode == 0, done.stderr[-3000:]
     lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
@@ -57,3 +57,21 @@ def test_two_rank_bench_with_persistent_chains_at_batch_512():
     assert out["parameters_identical_across_ranks"] is True
     assert out["profiled_step"]["plans"]["forward"][:2] == ["segmented", 256]
     assert out["launches_that_gave_up_waiting"] == 0
+
+
+def test_rccl_collectives_beside_the_persistent_chain_kernels_on_one_rank():
+    """The N > 1 exchange path over RCCL itself, as far as one GPU can run it: a single-rank `nccl` process group with
+    every collective issued (ICRL_FORCE_COLLECTIVES=1) - the broadcast, the early all-reduce of the policy network's
+    gradients on its own stream beside the value chain's persistent BPTT launch, the second piece, the max over
+    ranks - at the metric's size.  No persistent launch may give up waiting for its workgroups, and the step may
+    cost at most 5 % more than the same run with no process group.  (More than one RCCL rank needs more than
+    one GPU: that stays unmeasured here.)"""
+    size = ["--steps", "20", "--warmup", "5", "--soak", "0"]
+    plain = _launch(1, size, backend="nccl")
+    forced = _launch(1, size, backend="nccl", env_extra={"ICRL_FORCE_COLLECTIVES": "1"})
+    assert forced["n_gpus"] == 1 and forced["launches_that_gave_up_waiting"] == 0
+    assert forced["seam_fallbacks_in_run"] == plain["seam_fallbacks_in_run"]
+    assert forced["parameters_identical_across_ranks"] is None   # one rank: nothing to compare
+    print("ms per step: %.3f without a process group, %.3f with every collective issued over RCCL"
+          % (plain["ms_per_step"], forced["ms_per_step"]))
+    assert forced["ms_per_step"] <= 1.05 * plain["ms_per_step"]

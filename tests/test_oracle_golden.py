@@ -202,3 +202,21 @@ def test_cpu_port_matches_reference(name):
     for k, p in nets.named_trainable():
         check_summary(g, "grad", k, p.grad.numpy(), 1e-3, 1e-7)
         check_summary(g, "param1", k, p.detach().numpy(), 1e-5, 1e-6)
+
+
+def test_operand_rounding_switch_of_the_policy_rollout():
+    """operand_dtype rounds both operands of the policy products and nothing else: float32 operands leave float32
+    parameters' results where they were (only h is rounded: ~1e-7), bf16 operands move the log-probabilities by
+    bf16's 2^-9 per factor - well under a percent, well over float32 rounding."""
+    import torch
+    from helpers import synthetic
+    n, vocab, caplen, fdim = 4, 100, 10, 512
+    P = orc.to_t(synthetic.make_params("policy", vocab, fdim, 0))
+    feats, caps = synthetic.make_minibatch(n, vocab, caplen, fdim, 0)
+    forced = np.random.RandomState(0).randint(4, vocab, size=(n, caplen - 1))
+    run = lambda od: orc.policy_rollout(P, feats, caps[:, :1], caplen - 1, mode="forced", forced=forced,
+                                        operand_dtype=od)[2].numpy()
+    with torch.no_grad():
+        exact, f32, bf16 = run(None), run(torch.float32), run(torch.bfloat16)
+    assert np.abs(f32 - exact).max() < 2e-6
+    assert 1e-5 < np.abs(bf16 - exact).max() < 5e-2

@@ -46,6 +46,23 @@ def test_static_workspace_entry_point_equals_the_caller_workspace_one():
     _case(3, 64, 1, 12, 96, 64, True)
 
 
+def test_static_workspace_entry_point_allocates_nothing():
+    """Free device memory is the same before and after a call (a first call has already looked the array up)."""
+    rs = np.random.RandomState(5)
+    n, p0, calls, segs, warm = 64, 1, 12, 128, 48
+    positions = n * sum(p0 + s for s in range(calls))
+    xproj = torch.from_numpy((0.5 * rs.standard_normal(((p0 + calls - 1) * n, 4 * H))).astype(np.float32)).cuda()
+    w_hh = torch.from_numpy((rs.uniform(-1, 1, size=(4 * H, H)) / np.sqrt(H)).astype(np.float32)).cuda()
+    h_emit, saved = torch.zeros(calls, n, H, device="cuda"), torch.zeros(positions, 6, H, device="cuda")
+    err = torch.zeros(2, device="cuda")
+    hip.lstm_chain_fwd_seg_static(xproj, w_hh, n, p0, calls, segs, warm, h_emit, saved, err)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    hip.lstm_chain_fwd_seg_static(xproj, w_hh, n, p0, calls, segs, warm, h_emit, saved, err)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+
+
 def test_static_workspace_entry_point_rejects_more_segments_than_it_holds():
     x = torch.zeros(64 * 19, 4 * H, device="cuda")
     w = torch.zeros(4 * H, H, device="cuda")
