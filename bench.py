@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--pretrain", type=int, default=0,
                     help="run each of the three pre-training loops for this many minibatches first and bench the A2C "
                          "step on the networks they produce (trained-regime run, reported under its own workload name)")
+    ap.add_argument("--no-late-policy-bptt", action="store_true",
+                    help="the policy LSTM's BPTT as 3 T launches on the side stream beside the value chain's (the "
+                         "schedule before the persistent policy BPTT launch)")
     ap.add_argument("--no-collapse", action="store_true", help="walk every call of the chains in full")
     ap.add_argument("--no-warm16", action="store_true", help="every warm-up step on the float32 matrix instruction")
     args = ap.parse_args()
@@ -233,6 +236,8 @@ def main():
     engine_opts = dict(chain_semantics=args.chain_semantics, collapse_replays=not args.no_collapse)
     if args.no_warm16:
         engine_opts["warm16"] = False
+    if args.no_late_policy_bptt:
+        engine_opts["late_policy_bptt"] = False
     if args.policy_dtype != "f32":
         engine_opts["policy_dtype"] = args.policy_dtype
     if args.grad_products is not None:

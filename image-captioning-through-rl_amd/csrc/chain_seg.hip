@@ -1231,7 +1231,13 @@ constexpr int TILE2 = 32 * LDA2 + BK2 * 32;    // per wave: A [32 rows][32 k] pa
 constexpr int PBUF2 = 4 * TILE2;
 
 struct BwdArgs {
-    const float* w_hh; const float* saved; const float* d_emit;
+    const float* w_hh; const float* d_emit;
+    // the forward pass's activations of position p: gates {i, f, g, o} at saved + p * gate_stride (+ 0, H, 2H, 3H) and
+    // the cell state at cc + p * c_stride.  The chains keep them as one record {i, f, g, o, c, h} per position
+    // (gate_stride = c_stride = 6 H, cc = saved + 4 H); a caller with gates and cell states in arrays of their
+    // own (the policy LSTM: [T, N, 4H] and [T + 1, N, H]) points at those
+    const float* saved; const float* cc;
+    int gate_stride, c_stride;
     float* dgx;               // [2][K][4H] exchanged dgates
     float* dc; float* dgv; float* seam_a; float* dh_fin;
     unsigned* flags;          // [row tiles][32], 16 used
@@ -1323,9 +1329,10 @@ __global__ __launch_bounds__(256, 2) void seg_bwd_persist(BwdArgs a, unsigned* a
         float4 gi = zero4(), gf = zero4(), gg = zero4(), go = zero4(), cc = zero4(), cp = zero4(), de = zero4();
         if (live) {
             locate_fast(g, (int)pos, ps, pt, pi);
-            const float* sp = a.saved + pos * (6 * H) + u;
-            gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H); cc = ld4(sp + 4 * H);
-            if (pos >= g.stride) cp = ld4(a.saved + (pos - g.stride) * (6 * H) + 4 * H + u);
+            const float* sp = a.saved + pos * a.gate_stride + u;
+            gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H);
+            cc = ld4(a.cc + pos * a.c_stride + u);
+            if (pos >= g.stride) cp = ld4(a.cc + (pos - g.stride) * a.c_stride + u);
             if (pt == g.p0 + ps - 1) de = ld4(a.d_emit + ((int64_t)ps * g.n + pi) * H + u);
         }
 
@@ -1830,8 +1837,13 @@ int solo_persist(ChainArgs& a, int gates, float* work, hipStream_t st, unsigned*
 }
 
 // cheap: the first steps of the warm-up that run on seg_warm_bwd (16-bit split products) before the float32 launch
-int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, int cheap = 0, float* seam_err = nullptr) {
+int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, int cheap = 0, float* seam_err = nullptr,
+                float* dh_out = nullptr) {
     const int K = a.g.K;
+    if (a.cc == nullptr) {   // the chains' own records {i, f, g, o, c, h}
+        a.cc = a.saved + 4 * H;
+        a.gate_stride = a.c_stride = 6 * H;
+    }
     const int64_t kh = (int64_t)K * H;
     const int ny = (K + 31) / 32;
     unsigned* words = reinterpret_cast<unsigned*>(work + 12 * kh);
@@ -1844,7 +1856,7 @@ int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, i
                    {(int64_t)(word_bytes / sizeof(float)), seam_err ? 2 : 0, 0, 0, 0}};
         hipLaunchKernelGGL(zero_regions, dim3(8), dim3(256), 0, st, z);
     }
-    a.dgx = work; a.dc = work + 8 * kh; a.seam_a = work + 9 * kh; a.dh_fin = work + 11 * kh; a.flags = words;
+    a.dgx = work; a.dc = work + 8 * kh; a.seam_a = work + 9 * kh; a.dh_fin = dh_out ? dh_out : work + 11 * kh; a.flags = words;
     *abort_out = words + ny * 32;
     if (cheap > 0) {
         WarmBwdArgs wa{};
@@ -2352,6 +2364,41 @@ extern "C" int icrl_lstm_chain_bwd_rows(const float* w_hh, const float* saved, c
     } else {
         if (int rc = bwd_steps(a.g, w_hh, saved, d_emit, dgates, work, st)) return rc;
     }
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+// ------------------------------------------------------------------ the policy LSTM's BPTT as one launch
+// The backward-through-time of the policy network's LSTM over a rollout (autograd of models.py:80): N independent
+// rows, T steps each, a gradient injected at every step (what flows back from that step's vocabulary projection).
+// That is the per-row chain geometry with every column the last column of a call of its own (full_calls = 1), so
+// the persistent backward kernel walks it as it stands: T + 1 steps inside one launch instead of 3 T dependent
+// launches.  gates_act [T, N, 4H] and c_all [T + 1, N, H] are the rollout's activations (c_all[0] = the initial
+// cell state, zeros), d_h [T, N, H] the injected gradients; dgates [T, N, 4H] receives the gate gradients and
+// dh0 [N, H] what flows into the initial hidden state.  work: icrl_chain_seg_workspace_floats(N) floats.
+extern "C" int icrl_policy_lstm_bptt_persist(const float* gates_act, const float* c_all, const float* d_h,
+                                             const float* w_hh, int N, int T, float* dgates, float* dh0, float* work,
+                                             int* status, icrl_stream_t stream) {
+    ICRL_REQUIRE(gates_act && c_all && d_h && w_hh && dgates && dh0 && work && status,
+                 "icrl_policy_lstm_bptt_persist: null pointer");
+    ICRL_REQUIRE(N > 0 && N <= 4096 && T > 0 && (int64_t)N * T < ((int64_t)1 << 30),
+                 "icrl_policy_lstm_bptt_persist: need 0 < N <= 4096, T > 0, N T < 2^30");
+    ICRL_REQUIRE(aligned16(gates_act) && aligned16(c_all) && aligned16(d_h) && aligned16(w_hh) && aligned16(dgates) &&
+                 aligned16(dh0) && aligned16(work), "icrl_policy_lstm_bptt_persist: buffers must be 16-byte aligned");
+    ICRL_REQUIRE(icrl_chain_pair_supported(N),
+                 "icrl_policy_lstm_bptt_persist: %d rows need more workgroups than the device can hold at once", N);
+    BwdArgs a{};
+    Geom& g = a.g;
+    g.n = N; g.p0 = 1; g.n_calls = T; g.fc = 1; g.c0 = 1;
+    g.total = (int64_t)N * T; g.K = N; g.Ls = T; g.W = 0; g.stride = N;
+    a.w_hh = w_hh; a.d_emit = d_h; a.dgv = dgates;
+    a.saved = gates_act; a.gate_stride = 4 * H;
+    a.cc = c_all + (int64_t)N * H; a.c_stride = H;   // the cell state AFTER step t; the one before it is a row stride back
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    unsigned* abort_w = nullptr;
+    if (int rc = bwd_persist(a, work, st, &abort_w, 0, nullptr, dh0)) return rc;
+    hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

@@ -182,7 +182,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
-                 frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f32x3",
+                 frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f32x3", late_policy_bptt=True,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -223,6 +223,8 @@ class A2CEngine:
         # launch's 11.5, but it holds every CU's registers, and inside the A2C step, where the policy network's
         # backward pass shares the CUs with the chain, the step gets slower with it (soak 10.9 -> 12.7 ms)
         self.warm16_backward = bool(warm16_backward)
+        # the policy LSTM's backward-through-time as one persistent launch behind the value chain's (see _tail_ok)
+        self.late_policy_bptt = bool(late_policy_bptt)
         self._warm16b_off, self._warm16b_penalty = 0, 32
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
         self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
@@ -461,6 +463,19 @@ class A2CEngine:
         plan = lambda i: ("segmented", k, self.warmups[i]) if i < last else ("exact",)
         return fc, plan(fv), plan(fr), plan(bi)
 
+    def _tail_ok(self, n, pv, pr, pb):
+        """Whether this attempt runs the backward pass in the order value chain BPTT -> policy LSTM BPTT (both
+        persistent launches on the main stream) -> weight gradients, with everything of the policy network's
+        backward pass that needs no BPTT (G0 . W, the vocabulary gradients) formed beside the value chain's BPTT
+        instead of beside the forward chains.  As 3 T dependent launches on a stream of its own the policy LSTM's
+        BPTT took as long as the value chain's (19 steps at 120 us, launch latency, not work) and its weight
+        gradients then ended the step; as T + 1 steps of one launch it takes 0.3 ms, and the forward chains and
+        the heads have the device to themselves.  Needs the persistent launches (all segmented plans, and N rows
+        of the policy launch resident at once)."""
+        return (self.late_policy_bptt and self.concurrent and self.persistent and not self.per_sample
+                and self.P is not None and pv[0] == pr[0] == pb[0] == "segmented" and hip.chain_pair_supported(pv[1])
+                and hip.chain_pair_supported(n))
+
     @staticmethod
     def _next_plan(plans, attempt, checks):
         """After a rejected attempt: the seam error shrinks geometrically with the warm-up length
@@ -689,6 +704,7 @@ class A2CEngine:
                 hip.gemm(ws["hv"].view(n, H), w1[:, self.F:], ws["Y"])
                 hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], n, n, ws["values"])
                 hip.mse_loss(ws["values"], targets, ws["scalars"][0:1], ws["dvalue"])
+                self._value_head_vector(ws)
                 self._value_head_backward(ws, features, n, 1)
             self._value_chain_backward(ws, n, p0, 1, 1, main, main, pb, None)
             seg_v, seg_b = pv[0] == "segmented", pb[0] == "segmented"
@@ -853,6 +869,8 @@ class A2CEngine:
             side.wait_event(ev_start)
             hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
             hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
+            if backward:
+                self._value_head_vector(ws)
             ev_feat = torch.cuda.Event()
             ev_feat.record(side)
         tables_on = self._check_stream() if self.concurrent else main
@@ -893,10 +911,13 @@ class A2CEngine:
             fc, pv, pr, pb = self._choose(ws, n, p0, s, fv, fr, bi)
             if pv[0] == "exact":
                 bi = last
+            tail = with_bwd and self._tail_ok(n, pv, pr, pb)
+            if tail:
+                ws.pop("early_pending", None)   # G0 . W is formed beside the value chain's BPTT, not beside the forward chains
             ev_seam, ev_replay, replay_steps = self._chains_forward_loss(ws, features, n, p0, s, fc, backward, main, side,
                                                                          pv, pr)
             if with_bwd:
-                self._backward(ws, features, n, p0, s, fc, main, side, pb)
+                self._backward(ws, features, n, p0, s, fc, main, side, pb, tail)
             self._mark("backward_done")
             seg_v, seg_r = pv[0] == "segmented", pr[0] == "segmented"
             checks_v, checks_r = [], []
@@ -974,7 +995,7 @@ class A2CEngine:
                     restart = True     # the longer warm-up reaches further than the replays left out are long
                     break
                 pb = self._choose(ws, n, p0, s, fv, fr, bi)[3]
-                self._value_chain_backward(ws, n, p0, s, fc, main, side, pb, None)
+                self._value_chain_backward(ws, n, p0, s, fc, main, side, pb, None, tail=tail)
                 self._mark("backward_done")
             if restart:
                 continue
@@ -1213,7 +1234,7 @@ class A2CEngine:
         self._mark("side:reward_done")
 
     # ------------------------------------------------------------------ gradients
-    def _backward(self, ws, features, n, p0, s, fc, main, side, plan):
+    def _backward(self, ws, features, n, p0, s, fc, main, side, plan, tail=False):
         ev_loss = torch.cuda.Event()
         ev_loss.record(main)
 
@@ -1223,25 +1244,28 @@ class A2CEngine:
         late = self.concurrent
         self._value_head_backward(ws, features, n, s, weights=not late)
         ws["head_grads_pending"] = (features, n, s) if late else None
-        if late:   # whoever forms the head's weight gradients on another stream reads dY: after this point
-            ws["ev_head_dY"] = torch.cuda.Event()
-            ws["ev_head_dY"].record(main)
-        self._value_chain_backward(ws, n, p0, s, fc, main, side, plan, ev_loss, features)
+        self._value_chain_backward(ws, n, p0, s, fc, main, side, plan, ev_loss, features, tail=tail)
         ev_head = ws.pop("ev_head_grads", None)
         if ev_head is not None:
             main.wait_event(ev_head)
         elif ws.pop("head_grads_pending", None) is not None:   # nobody picked them up: here and now
             self._value_head_weight_grads(ws, features, n, s, ws["scratch_main"], ws["cs_main"])
 
+    def _value_head_vector(self, ws):
+        """uh = w2 . W1h, the 512-vector through which the value head's output depends on the chain's hidden state:
+        there is no non-linearity between the head's two linear layers (models.py:175-178), so what flows back into
+        the chain is dvalue[r] * uh, row by row.  It depends on the parameters only."""
+        V = self.V
+        if "uh" not in ws:
+            ws["uh"] = torch.empty(1, H, dtype=torch.float32, device=self.device)
+        hip.gemm(V["linear2.weight"], V["linear1.weight"][:, self.F:], ws["uh"], b_kmajor=True)
+
     def _value_head_backward(self, ws, features, n, s, weights=True):
         """Backward of the two linear layers of the value head (models.py:175-178) from ws["dvalue"]:
-        d_emit, the gradient entering the chain at each call's last column, and (weights=True) their weight
-        gradients."""
-        V = self.V
-        dvalue = ws["dvalue"].view(s * n, 1)
-        dY = ws["dY"]
-        hip.gemm(dvalue, V["linear2.weight"], dY, b_kmajor=True)                       # dY = dvalue (x) w2
-        hip.gemm(dY, V["linear1.weight"][:, self.F:], ws["d_emit"].view(s * n, H), b_kmajor=True)
+        d_emit, the gradient entering the chain at each call's last column - dvalue[r] * (w2 . W1h), an outer
+        product with a vector formed off the critical path (_value_head_vector) instead of two products over all
+        rows in front of the chain's BPTT - and (weights=True) the layers' weight gradients."""
+        hip.scale_rows(ws["uh"].expand(s * n, H), ws["dvalue"], ws["d_emit"].view(s * n, H))
         if weights:
             self._value_head_weight_grads(ws, features, n, s, ws["scratch_main"], ws["cs_main"])
 
@@ -1251,6 +1275,7 @@ class A2CEngine:
         V, gV = self.V, self.gV
         dvalue = ws["dvalue"].view(s * n, 1)
         dY = ws["dY"]
+        hip.scale_rows(V["linear2.weight"].expand(s * n, 512), ws["dvalue"], dY)        # dY = dvalue (x) w2
         hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], scratch, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
         hip.colsum(dvalue, gV["linear2.bias"], scratch=cs)
         gw1 = gV["linear1.weight"]
@@ -1260,14 +1285,16 @@ class A2CEngine:
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
         hip.colsum(dY, gV["linear1.bias"], scratch=cs)
 
-    def _value_chain_backward(self, ws, n, p0, s, fc, main, side, plan, ev_loss, features=None):
-        """The value chain's BPTT and everything that consumes it.  With ev_loss the side stream also
-        runs the policy network's BPTT beside the chain (first attempt of a step); without, only the
-        chain's part is redone (after a rejected seam check)."""
+    def _value_chain_backward(self, ws, n, p0, s, fc, main, side, plan, ev_loss, features=None, tail=False):
+        """The value chain's BPTT and everything that consumes it.  With ev_loss the policy network's backward
+        pass is queued as well (first attempt of a step): on the side stream beside the chain, or (tail, see
+        _tail_ok) its loss-dependent products beside the chain and its LSTM's BPTT as one launch behind the
+        chain's.  Without ev_loss only the chain's part is redone (after a rejected seam check)."""
         V, gV = self.V, self.gV
         lv, tv = p0 + s - 1, hip.chain_positions(n, p0, s, fc)
         tok_flat = ws["tokT"].view(-1)
         saved, dgv = ws["saved"][:tv], ws["dgv"][:tv]
+        tail = tail and ev_loss is not None
         if plan[0] == "rows":
             hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
                                     ws["work_v"], ws["status"][2:3],
@@ -1284,6 +1311,21 @@ class A2CEngine:
                                ws["sync_v"], ws["status"][2:3])
 
         self._mark("value_chain_bwd_done")
+        if tail:
+            # queued BEHIND the chain's launch although it waits for the loss only: launches that the host queues
+            # first get the device first, and with two vocabulary-sized products (36 KB of LDS per workgroup, four
+            # per CU) in front of it the chain's persistent launch (84 KB per workgroup) found no CU to start on for
+            # 0.9 ms (kernel trace: BPTT from 4.43 ms into the step, against 3.60 ms in this order)
+            ev_dhall, ev_vocab = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
+            # the policy LSTM's backward-through-time: one persistent launch, right behind the value chain's
+            main.wait_event(ev_dhall)
+            if "work_p" not in ws:
+                ws["work_p"] = torch.empty(hip.chain_seg_workspace_floats(n), dtype=torch.float32, device=self.device)
+            hip.policy_lstm_bptt_persist(ws["gates"], ws["Cbuf"], ws["dHall"], self.P["lstm.weight_hh_l0"], ws["dgp"],
+                                         ws["dh0"], ws["work_p"], ws["status"][3:4])
+            self._mark("policy_bptt_done")
+            ev_pbptt = torch.cuda.Event()
+            ev_pbptt.record(main)
         if plan[0] == "segmented":
             # every word the host reads back (backward seam error, the chain kernels' status words) is final here
             ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
@@ -1291,7 +1333,11 @@ class A2CEngine:
             ws["ev_ctl"].record(main)
         # ---- side stream: the policy network's BPTT beside the value chain
         ev_side = None
-        if ev_loss is not None:
+
+        def side_section():
+            nonlocal ev_side
+            if ev_loss is None:
+                return
             with torch.cuda.stream(side):
                 side.wait_event(ev_loss)
                 self._mark("side:policy_bwd_start")
@@ -1302,6 +1348,8 @@ class A2CEngine:
                 self._ev_policy = torch.cuda.Event()
                 self._ev_policy.record(side)
                 ev_side = self._ev_policy
+        if not tail:
+            side_section()
 
         # ---- main stream: the recurrent weight gradient, sum over the positions of dgates (x) h_prev.  The
         # previous position's h is read in place from the kept activations (slot 5 of the position before,
@@ -1335,6 +1383,18 @@ class A2CEngine:
             hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], sm, b_kmajor=True, dtype=self.gd)
             hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
         self._mark("value_input_grads_done")
+        if tail:
+            # queued behind the main stream's own products above: the device takes up a stream's launches in the
+            # order the host queued them across streams (queued first, these held the main stream's first product back
+            # by 0.7 ms in a kernel trace)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_pbptt)
+                self._policy_weight_grads(ws, features, n, p0, s)
+                side.wait_event(ev_vocab)
+                self._mark("side:policy_bwd_done")
+                self._ev_policy = torch.cuda.Event()
+                self._ev_policy.record(side)
+                ev_side = self._ev_policy
         if ev_side is not None:
             main.wait_event(ev_side)
 
@@ -1347,10 +1407,6 @@ class A2CEngine:
         LSTM's backward-through-time."""
         P, gP = self.P, self.gP
         t_steps = p0 - 1 + s
-        if ws.get("X_pending"):
-            hip.gather_rows(P["caption_embedding.weight"], ws["tokT"].view(-1), 1, t_steps * n,
-                            ws["X"].view(t_steps * n, -1))
-            ws["X_pending"] = False
         coef = ws["dlogp"]
         G0 = ws["dlogits"].view(s * n, self.vocab)
         Hs = ws["Hbuf"][p0:].view(s * n, H)          # LSTM outputs that fed the vocabulary projection
@@ -1379,17 +1435,29 @@ class A2CEngine:
             ev_vocab.record(other)
             pending = ws.pop("head_grads_pending", None) if other is not cur else None
             if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
-                other.wait_event(ws["ev_head_dY"])
                 self._value_head_weight_grads(ws, *pending, sc, cs)
                 ws["ev_head_grads"] = torch.cuda.Event()
                 ws["ev_head_grads"].record(other)
             if other is not cur:
                 self._mark("check:vocab_grads_done")
-        dgp = ws["dgp"]
         # the LSTM's backward-through-time: 3 launches per step, queued by the library in one call (from Python the
         # 57 launches of a 19-step rollout cost about half a millisecond of host time)
-        hip.policy_lstm_bptt(ws["gates"], ws["Cbuf"], dHall, P["lstm.weight_hh_l0"], dgp, ws["dc0"], ws["dc1"], ws["dh0"],
-                             ss, shared=True, dtype=self.pd)
+        hip.policy_lstm_bptt(ws["gates"], ws["Cbuf"], dHall, P["lstm.weight_hh_l0"], ws["dgp"], ws["dc0"], ws["dc1"],
+                             ws["dh0"], ss, shared=True, dtype=self.pd)
+        self._policy_weight_grads(ws, features, n, p0, s)
+        cur.wait_event(ev_vocab)
+
+    def _policy_weight_grads(self, ws, features, n, p0, s):
+        """What follows the policy LSTM's BPTT, on the current stream: the gradients of its weights, biases and
+        embedding table and of cnn2linear, from ws["dgp"] (gate gradients of all steps) and ws["dh0"]."""
+        P, gP = self.P, self.gP
+        t_steps = p0 - 1 + s
+        ss = ws["scratch_side"]
+        if ws.get("X_pending"):
+            hip.gather_rows(P["caption_embedding.weight"], ws["tokT"].view(-1), 1, t_steps * n,
+                            ws["X"].view(t_steps * n, -1))
+            ws["X_pending"] = False
+        dgp = ws["dgp"]
         dg_all = dgp.view(t_steps * n, 4 * H)
         hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True,
                       shared=True, dtype=self.vgd)
@@ -1403,4 +1471,54 @@ class A2CEngine:
             hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
         hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])
-        cur.wait_event(ev_vocab)
+
+    def _policy_backward_beside_chain(self, ws, n, p0, s, ev_loss, side):
+        """The part of the policy network's backward pass that needs the loss but no BPTT, queued beside the value
+        chain's BPTT (see _tail_ok).  Third stream: U = G0 . W (unless an earlier attempt of this minibatch has
+        formed it), what flows into the LSTM outputs (coef * U), coef * Hs, then the value head's weight
+        gradients.  Side stream: the vocabulary matrix's gradients G0^T . (coef * Hs) and sum_r coef[r] G0[r, :].
+        Returns (event after which ws["dHall"] is complete, event after which the vocabulary gradients are)."""
+        P, gP = self.P, self.gP
+        coef = ws["dlogp"]
+        G0 = ws["dlogits"].view(s * n, self.vocab)
+        Hs = ws["Hbuf"][p0:].view(s * n, H)
+        check = self._check_stream()
+        with torch.cuda.stream(check):
+            check.wait_event(ev_loss)
+            if ws.get("policy_early"):
+                check.wait_event(ws["ev_early"])
+            else:
+                hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ws["scratch_check"], b_kmajor=True, shared=True,
+                              dtype=self.vgd)
+                ws["policy_early"], ws["ev_early"] = True, torch.cuda.Event()
+                ws["ev_early"].record(check)
+            dHall = ws["dHall"]
+            if p0 > 1:
+                dHall[:p0 - 1].zero_()
+            hip.scale_rows(ws["Uvocab"], coef, dHall[p0 - 1:].view(s * n, H))
+            ev_dhall = torch.cuda.Event()
+            ev_dhall.record(check)
+            self._mark("check:policy_dH_done")
+            pending = ws.pop("head_grads_pending", None)
+            if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
+                self._value_head_weight_grads(ws, *pending, ws["scratch_check"], ws["cs_check"])
+                ws["ev_head_grads"] = torch.cuda.Event()
+                ws["ev_head_grads"].record(check)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_loss)
+            self._mark("side:policy_bwd_start")
+            if ws.get("ev_order") is not None:
+                side.wait_event(ws.pop("ev_order"))
+            if ws.get("X_pending"):   # the embedding rows of the steps that took their input side from the per-word table
+                t_steps = p0 - 1 + s
+                hip.gather_rows(P["caption_embedding.weight"], ws["tokT"].view(-1), 1, t_steps * n,
+                                ws["X"].view(t_steps * n, -1))
+                ws["X_pending"] = False
+            hip.scale_rows(Hs, coef, ws["HsC"])
+            hip.gemm_auto(G0, ws["HsC"], gP["linear2vocab.weight"], ws["scratch_side"], a_kmajor=True, b_kmajor=True,
+                          shared=True, dtype=self.vgd)
+            hip.colsum(G0, gP["linear2vocab.bias"], scratch=ws["cs_side"], row_scale=coef)
+            ev_vocab = torch.cuda.Event()
+            ev_vocab.record(side)
+            self._mark("side:vocab_grads_done")
+        return ev_dhall, ev_vocab

@@ -65,6 +65,7 @@ SIGNATURES = {
     "icrl_gru_cell_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_policy_lstm_bptt": (c_int, [c_vp] * 9 + [c_i64] + [c_int] * 5 + [c_vp]),
+    "icrl_policy_lstm_bptt_persist": (c_int, [c_vp] * 4 + [c_int] * 2 + [c_vp] * 5),
     "icrl_policy_lstm_step": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                       c_vp]),
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
@@ -773,6 +774,21 @@ def policy_lstm_bptt(gates_act, c_all, d_h, w_hh, dgates, dc0, dc1, dh0, scratch
                                           _ptr(_f32c(scratch)), scratch.numel(), n, t_steps, splits, int(tile),
                                           int(dtype == "bf16"), _stream())
     _check(rc, "icrl_policy_lstm_bptt")
+
+
+def policy_lstm_bptt_persist(gates_act, c_all, d_h, w_hh, dgates, dh0, work, status):
+    """The policy LSTM's backward-through-time over all T steps as ONE persistent launch (the backward chain kernel
+    on N per-row chains with a gradient injected at every step); d_h is read only.  Needs chain_pair_supported(N)."""
+    t_steps, n = gates_act.shape[0], gates_act.shape[1]
+    assert gates_act.shape == (t_steps, n, 2048) and c_all.shape[0] >= t_steps + 1 and c_all.shape[1:] == (n, 512)
+    assert d_h.shape == (t_steps, n, 512) and dgates.shape == (t_steps, n, 2048) and w_hh.shape == (2048, 512)
+    assert dh0.shape == (n, 512) and work.numel() >= chain_seg_workspace_floats(n)
+    assert status.dtype == torch.int32 and status.numel() >= 1
+    with _Timed("policy_bptt", t_steps, steps=t_steps + 1, flops=2.0 * t_steps * n * 512 * 2048):
+        rc = load().icrl_policy_lstm_bptt_persist(_ptr(_f32c(gates_act)), _ptr(_f32c(c_all)), _ptr(_f32c(d_h)),
+                                                  _ptr(_f32c(w_hh)), n, t_steps, _ptr(_f32c(dgates)), _ptr(_f32c(dh0)),
+                                                  _ptr(_f32c(work)), _ptr(status), _stream())
+    _check(rc, "icrl_policy_lstm_bptt_persist")
 
 
 def policy_lstm_step(emb, tokens, w_ih, w_hh, b_ih, b_hh, h_cur, c_cur, gates_act, c_next, h_next, x_out=None):

@@ -160,6 +160,16 @@ int icrl_policy_lstm_bptt(const float* gates_act, const float* c_all, float* dH,
                           float* dgates, float* dc0, float* dc1, float* dh0, float* scratch,
                           int64_t scratch_floats, int N, int T, int splits, int tile, int bf16,
                           icrl_stream_t stream);
+/* The same backward-through-time (autograd of models.py:80, trainers.py:479) as ONE persistent launch: the N rows
+ * are N independent chains of T steps with a gradient injected at every step, which is the per-row chain
+ * geometry of icrl_lstm_chain_bwd_rows with every column the last column of a call of its own; the launch walks
+ * T + 1 steps, dgates handed between its workgroups as in icrl_lstm_chain_bwd_seg_persist (exact float32
+ * products).  d_h [T,N,H] is read only (the running dH of step k lives inside the launch); dgates [T,N,4H] and
+ * dh0 [N,H] as for icrl_policy_lstm_bptt.  work: icrl_chain_seg_workspace_floats(N) floats.  *status != 0
+ * afterwards: the launch gave up waiting for a workgroup (results unusable).  Needs icrl_chain_pair_supported(N). */
+int icrl_policy_lstm_bptt_persist(const float* gates_act, const float* c_all, const float* d_h, const float* w_hh,
+                                  int N, int T, float* dgates, float* dh0, float* work, int* status,
+                                  icrl_stream_t stream);
 
 /* One whole step of the policy LSTM in a single launch (models.py:73 + :80 for one position):
  * x = emb[tokens[i]], gates = x*W_ih^T + h_cur*W_hh^T + b_ih + b_hh, then the cell.  Writes the

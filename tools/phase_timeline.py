@@ -1,6 +1,6 @@
 """Per-phase GPU timeline of one A2C minibatch at the bench workload (HIP events on the launching streams).
 
-    python tools/phase_timeline.py [f32|bf16] [minibatches before the traced one, default 5] [f32|f32x3 gradient products]
+    python tools/phase_timeline.py [f32|bf16] [minibatches before the traced one, default 5] [f32|f32x3 gradient products] [late policy BPTT 1|0]
 """
 import sys, importlib, numpy as np, torch
 sys.path.insert(0, '/root/repo')
@@ -13,6 +13,8 @@ n, vocab, caplen, fdim = 512, 10000, 20, 2048
 a2c, rew, flat, params = bench.build_networks(syn, models, optim, vocab, fdim, 0, dev)
 opt = optim.FusedAdam(flat, lr=1e-4)
 opts = {"grad_products": sys.argv[3]} if len(sys.argv) > 3 else {}
+if len(sys.argv) > 4:   # 0: the policy LSTM's BPTT as 3 T launches on the side stream (the earlier schedule)
+    opts["late_policy_bptt"] = bool(int(sys.argv[4]))
 engine = trainers.build_engine(a2c, rew, policy_dtype=sys.argv[1] if len(sys.argv) > 1 else "f32", **opts)
 feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, 0)
 fd = torch.from_numpy(feats).to(dev); pd = torch.from_numpy(caps[:, :1]).to(dev)
