@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--pretrain", type=int, default=0,
                     help="run each of the three pre-training loops for this many minibatches first and bench the A2C "
                          "step on the networks they produce (trained-regime run, reported under its own workload name)")
+    ap.add_argument("--chain-arith", default=None, choices=("f32", "f16x2"),
+                    help="recurrent products of the forward chains' persistent launch (default: the engine's)")
     ap.add_argument("--no-late-policy-bptt", action="store_true",
                     help="the policy LSTM's BPTT as 3 T launches on the side stream beside the value chain's (the "
                          "schedule before the persistent policy BPTT launch)")
@@ -236,6 +238,8 @@ def main():
     engine_opts = dict(chain_semantics=args.chain_semantics, collapse_replays=not args.no_collapse)
     if args.no_warm16:
         engine_opts["warm16"] = False
+    if args.chain_arith is not None:
+        engine_opts["chain_arith"] = args.chain_arith
     if args.no_late_policy_bptt:
         engine_opts["late_policy_bptt"] = False
     if args.policy_dtype != "f32":

@@ -1205,6 +1205,231 @@ __global__ __launch_bounds__(256, 2) void seg_warm_pair(WarmArgs v, WarmArgs r, 
     else if (r.steps > 0) warm_chain<3>(r, bx, by, abort_w, warm_lds);
 }
 
+
+// ------------------------------------------------------------------ both forward chains, every step, on the f16 matrix instruction
+// The same workgroup shape as seg_warm_pair (unit tile of 16 units, row group of 32 segments, wave q = gate q with
+// its slice of W_hh in registers for the whole launch), but at float32-level accuracy, so that it walks the WHOLE
+// chain - warm-up and own positions - and writes what seg_fwd_pair_persist writes (kept activations, emitted h,
+// seam records).  Every operand is cut in two f16 pieces after a power-of-two scaling that keeps both pieces in
+// f16's normal range: h (|h| < 1) by 2^12, a row of W_hh by the power of two that brings its largest entry into
+// [2^10, 2^11).  x s = hi + mid + r with |r| <= 2^-22 |x s|, and the product is hi.hi + hi.mid + mid.hi on
+// v_mfma_f32_16x16x32_f16 (the piece products are exact, the sums float32); what is dropped - mid.mid and the two
+// r terms - is below 2^-21 of each element product, the size of float32's own rounding of the 512-term sum.  Three
+// matrix instructions of 16 x 16 x 32 do the work of sixteen 32 x 32 x 2 float32 ones, and a step moves only the row
+// group's h (W_hh never leaves the registers).  The scalings are powers of two, so undoing them is exact.
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x4 __attribute__((ext_vector_type(4)));
+constexpr float HP_H_SCALE = 4096.f;           // 2^12
+
+struct HpArgs {
+    const float* xproj; const float* w_hh; const float* b_hh;
+    float* hb;                // [2][K][H] exchanged h
+    float* saved; float* h_emit; float* seam_a; float* seam_b;
+    unsigned* flags;          // [row groups][32]
+    Geom g;
+};
+
+__device__ __forceinline__ void split2h(float x, _Float16& hi, _Float16& mid) {
+    hi = (_Float16)x;
+    mid = (_Float16)(x - (float)hi);
+}
+
+template <int G>
+__device__ __forceinline__ void hp_chain(const HpArgs& a, int bx, int by, unsigned* abort_w, char* lds_raw) {
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int row0 = by * 32, u0 = bx * 16;
+    _Float16* plane = reinterpret_cast<_Float16*>(lds_raw);                                   // [2][32][WLD]
+    float* gt = reinterpret_cast<float*>(lds_raw + 2 * 32 * WLD * sizeof(_Float16));          // [G][32][WGT]
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.hb, 0, (int)(2 * (int64_t)g.K * H * sizeof(float)), 0x00020000);
+
+    // B operand of lane (column l15, k group kg) at k step ks: W_hh[gate q, unit u0 + l15][32 ks + 8 kg + 0..7], the
+    // row scaled by a power of two of its own; `descale` undoes that and h's scaling on the column's sums
+    hf16x8 bw[2][16];
+    float descale = 1.f;
+    if (q < G) {
+        const float* wrow = a.w_hh + ((int64_t)q * H + u0 + l15) * H + 8 * kg;
+        float top = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float4 w0 = ld4(wrow + 32 * ks), w1 = ld4(wrow + 32 * ks + 4);
+            top = fmaxf(top, fmaxf(fmaxf(fabsf(w0.x), fabsf(w0.y)), fmaxf(fabsf(w0.z), fabsf(w0.w))));
+            top = fmaxf(top, fmaxf(fmaxf(fabsf(w1.x), fabsf(w1.y)), fmaxf(fabsf(w1.z), fabsf(w1.w))));
+        }
+        top = fmaxf(top, __shfl_xor(top, 16));   // the four lanes of a column hold a quarter of its row each
+        top = fmaxf(top, __shfl_xor(top, 32));
+        int ex = 0;
+        if (top > 0.f && top < INFINITY) frexpf(top, &ex);    // top = f 2^ex, f in [0.5, 1)
+        ex = max(-100, min(100, ex));
+        const float scale = ldexpf(1.f, 11 - ex);             // top * scale in [2^10, 2^11)
+        descale = ldexpf(1.f, ex - 11 - 12);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const float4 w0 = ld4(wrow + 32 * ks), w1 = ld4(wrow + 32 * ks + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 hi, mid;
+                split2h(w[e] * scale, hi, mid);
+                bw[0][ks][e] = hi;
+                bw[1][ks][e] = mid;
+            }
+        }
+    }
+
+    // this lane's epilogue item: segment row j, units u, u + 1; its cell state lives in registers
+    const int rr = tid >> 3, uq = 2 * (tid & 7);
+    const int j = row0 + rr, u = u0 + uq;
+    float2 state = make_float2(0.f, 0.f);      // LSTM: c, GRU: h
+    int ps = 0, pt = 0, pi = 0;
+    float2 bias[3];
+    if (G == 3) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) bias[gq] = *reinterpret_cast<const float2*>(a.b_hh + gq * H + u);
+    }
+#define ST2(p, v) (*reinterpret_cast<float2*>(p) = (v))
+
+    const int steps = g.W + g.Ls;
+    for (int m = 0; m < steps; ++m) {
+        const int cur = m & 1, nxt = cur ^ 1;
+        const int qs = m - g.W;     // step within the segment: negative during the warm-up
+        const int64_t pos = seg_pos(g, j, qs);
+        int st = 0;   // 0 = no row, 1 = outside the segment's range (zero state), 2 = live
+        float2 px[G];
+        if (j < g.K) {
+            st = (pos < 0 || qs >= g.Ls || pos >= g.total) ? 1 : 2;
+            if (st == 2) {
+                locate_fast(g, (int)pos, ps, pt, pi);
+                const float* xr = a.xproj + ((int64_t)pt * g.n + pi) * (G * H) + u;
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) px[gq] = *reinterpret_cast<const float2*>(xr + gq * H);
+            }
+        }
+        f32x4 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] = 0.f;
+
+        if (m > 0) {
+            if (q == 0) wait_row_group32(a.flags + by * 32, (unsigned)m, abort_w, lane);
+            __syncthreads();
+            // the row group's h: float4 (tid + 256 i) of 32 rows x 128, scaled and cut into the hi and mid planes
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {   // eight loads in flight at a time
+                v4u raw[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = tid + 256 * (8 * half + i), row = f >> 7, c4 = f & 127;
+                    raw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (min(row0 + row, g.K - 1) * H + 4 * c4) * 4,
+                                                                   cur * g.K * H * 4, SC1);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = tid + 256 * (8 * half + i), row = f >> 7, c4 = f & 127;
+                    const float4 v = as_f4(raw[i]);
+                    hf16x4 hi, mid;
+                    _Float16 h_, m_;
+                    split2h(v.x * HP_H_SCALE, h_, m_); hi[0] = h_; mid[0] = m_;
+                    split2h(v.y * HP_H_SCALE, h_, m_); hi[1] = h_; mid[1] = m_;
+                    split2h(v.z * HP_H_SCALE, h_, m_); hi[2] = h_; mid[2] = m_;
+                    split2h(v.w * HP_H_SCALE, h_, m_); hi[3] = h_; mid[3] = m_;
+                    *reinterpret_cast<hf16x4*>(plane + row * WLD + 4 * c4) = hi;
+                    *reinterpret_cast<hf16x4*>(plane + (32 + row) * WLD + 4 * c4) = mid;
+                }
+            }
+            __syncthreads();
+            if (q < G) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const _Float16* ar = plane + (mt * 16 + l15) * WLD + 8 * kg;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const hf16x8 a_hi = *reinterpret_cast<const hf16x8*>(ar + 32 * ks);
+                        const hf16x8 a_mid = *reinterpret_cast<const hf16x8*>(ar + 32 * WLD + 32 * ks);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bw[0][ks], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bw[1][ks], acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_mid, bw[0][ks], acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // accumulator register r of lane (l15, kg) is element [row 4 kg + r][column l15] of its 16 x 16 tile
+        if (q < G) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gt[(q * 32 + mt * 16 + 4 * kg + r) * WGT + l15] = acc[mt][r] * descale;
+        }
+        __syncthreads();
+
+        if (st != 0) {
+            float2 h = make_float2(0.f, 0.f);
+            if (st == 1) {
+                state = make_float2(0.f, 0.f);
+            } else {
+                const float* pr = gt + rr * WGT + uq;
+                if (G == 4) {
+                    float2 gi = make_float2(pr[0] + px[0].x, pr[1] + px[0].y);
+                    float2 gf = make_float2(pr[32 * WGT] + px[1].x, pr[32 * WGT + 1] + px[1].y);
+                    float2 gg = make_float2(pr[64 * WGT] + px[2].x, pr[64 * WGT + 1] + px[2].y);
+                    float2 go = make_float2(pr[96 * WGT] + px[G - 1].x, pr[96 * WGT + 1] + px[G - 1].y);
+                    float2 c;
+                    LSTM_CELL1(x, gi, gf, gg, go, state, c, h)
+                    LSTM_CELL1(y, gi, gf, gg, go, state, c, h)
+                    state = c;
+                    if (qs >= 0 && a.saved) {
+                        float* sp = a.saved + pos * (6 * H) + u;
+                        ST2(sp, gi); ST2(sp + H, gf); ST2(sp + 2 * H, gg); ST2(sp + 3 * H, go); ST2(sp + 4 * H, c); ST2(sp + 5 * H, h);
+                    }
+                    if (qs == -1) ST2(a.seam_a + (int64_t)j * 2 * H + H + u, c);
+                    if (qs == g.Ls - 1 && j + 1 < g.K) ST2(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
+                } else {
+                    const float2 hr_ = make_float2(pr[0] + bias[0].x, pr[1] + bias[0].y);
+                    const float2 hz = make_float2(pr[32 * WGT] + bias[1].x, pr[32 * WGT + 1] + bias[1].y);
+                    const float2 hn = make_float2(pr[64 * WGT] + bias[2].x, pr[64 * WGT + 1] + bias[2].y);
+                    GRU_CELL1(x, px[0], px[1], px[2], hr_, hz, hn, state, h)
+                    GRU_CELL1(y, px[0], px[1], px[2], hr_, hz, hn, state, h)
+                    if (qs >= 0 && a.saved) {   // {r, z, n, hn, h}: the same expressions as in the cell
+                        float2 r2, z2, n2;
+                        GRU_GATES1(x, px[0], px[1], px[2], hr_, hz, hn, r2, z2, n2)
+                        GRU_GATES1(y, px[0], px[1], px[2], hr_, hz, hn, r2, z2, n2)
+                        float* sp = a.saved + pos * (5 * H) + u;
+                        ST2(sp, r2); ST2(sp + H, z2); ST2(sp + 2 * H, n2); ST2(sp + 3 * H, hn); ST2(sp + 4 * H, h);
+                    }
+                    state = h;
+                }
+                if (qs >= 0 && a.h_emit != nullptr && pt == g.p0 + ps - 1) ST2(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
+                constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
+                if (qs == -1) ST2(a.seam_a + (int64_t)j * SW + u, h);
+                if (qs == g.Ls - 1 && j + 1 < g.K) ST2(a.seam_b + (int64_t)(j + 1) * SW + u, h);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, h), rs, (j * H + u) * 4, nxt * g.K * H * 4, SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
+        __syncthreads();                                    // ... before ONE lane signals for all of them
+        if (tid == 0)
+            __hip_atomic_store((gu32*)(a.flags + by * 32 + bx), (unsigned)(m + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+#undef ST2
+}
+
+// Block b runs on XCD b % 8; a row group's 32 workgroups are given block ids of one XCD (speed only: every hand-off
+// store is write-through).
+__global__ __launch_bounds__(256, 2) void seg_fwd_pair_hp(HpArgs v, HpArgs r, unsigned* abort_w, int per_chain, int ny) {
+    extern __shared__ __attribute__((aligned(16))) char hp_lds[];
+    __builtin_amdgcn_s_setprio(3);
+    const int chain = blockIdx.x / per_chain, w = blockIdx.x % per_chain;
+    const int xcd = w & 7, t = w >> 3;
+    const int by = (t >> 5) * 8 + xcd, bx = t & 31;
+    if (by >= ny) return;
+    if (chain == 0) hp_chain<4>(v, bx, by, abort_w, hp_lds);
+    else hp_chain<3>(r, bx, by, abort_w, hp_lds);
+}
+
 // only: 0 = both chains (2 * per_chain workgroups), 1 = the LSTM chain alone, 2 = the GRU chain alone
 // (per_chain workgroups)
 __global__ __launch_bounds__(256, 2) void seg_fwd_pair_persist(ChainArgs v, ChainArgs r, unsigned* abort_w, int per_chain,
@@ -1815,6 +2040,27 @@ int pair_persist(ChainArgs& v, ChainArgs& r, float* work_v, float* work_r, hipSt
     return ICRL_OK;
 }
 
+
+// both forward chains, every step, in the f16 launch (seg_fwd_pair_hp); workspace layout as pair_persist's
+int pair_hp(HpArgs& v, HpArgs& r, float* work_v, float* work_r, hipStream_t st, unsigned** abort_out, float* err_a,
+            float* err_b) {
+    const int K = v.g.K;
+    const int64_t kh = (int64_t)K * H;
+    const int ny = (K + 31) / 32;
+    unsigned* words = reinterpret_cast<unsigned*>(work_v + 12 * kh);
+    const size_t word_bytes = ((size_t)(2 * ny * 32 + 4) * sizeof(unsigned) + 255) / 256 * 256;
+    ICRL_REQUIRE((int64_t)(word_bytes / sizeof(float)) <= 4 * kh, "persistent chain launch: workspace too small");
+    ZeroArgs z{{reinterpret_cast<float*>(words), work_v, work_r, err_a, err_b},
+               {(int64_t)(word_bytes / sizeof(float)), 2 * kh, 2 * kh, 1, 1}};
+    hipLaunchKernelGGL(zero_regions, dim3(128), dim3(256), 0, st, z);
+    v.hb = work_v; v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
+    r.hb = work_r; r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 32;
+    *abort_out = words + 2 * ny * 32;
+    const int per_chain = (ny + 7) / 8 * 8 * 32;
+    hipLaunchKernelGGL(seg_fwd_pair_hp, dim3(2 * per_chain), dim3(256), WARM_LDS, st, v, r, *abort_out, per_chain, ny);
+    return ICRL_OK;
+}
+
 // one forward chain alone in the persistent launch (gates = 4: LSTM, 3: GRU); same workspace layout as
 // the per-step schedules above
 int solo_persist(ChainArgs& a, int gates, float* work, hipStream_t st, unsigned** abort_out) {
@@ -2099,6 +2345,56 @@ extern "C" int icrl_chain_pair_fwd_seg_warm16(const float* xproj_v, const float*
     return pair_fwd_impl("icrl_chain_pair_fwd_seg_warm16", xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, N, p0_v, p0_r,
                          n_calls, full_calls, segments, warmup_v, warmup_r, cheap_v, cheap_r, phase, h_emit_v, saved_v,
                          h_emit_r, saved_r, work_v, work_r, seam_err_v, seam_err_r, stream);
+}
+
+
+extern "C" int icrl_chain_f16x2_supported(int segments) {
+    // all 2 x 32 x ceil(segments / 32) workgroups of the f16 forward launch (rounded up to whole groups of 8 row
+    // groups) must be resident at once
+    static int cus = -1, per_cu = 0;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(seg_fwd_pair_hp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WARM_LDS) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seg_fwd_pair_hp, 256, WARM_LDS) != hipSuccess) return 0;
+        cus = n;
+    }
+    if (segments < 1) return 0;
+    const int ny = (segments + 31) / 32;
+    return 2 * ((ny + 7) / 8 * 8 * 32) <= cus * per_cu ? 1 : 0;
+}
+
+extern "C" int icrl_chain_pair_fwd_seg_f16x2(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                             const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r,
+                                             int n_calls, int full_calls, int segments, int warmup_v, int warmup_r,
+                                             float* h_emit_v, float* saved_v, float* h_emit_r, float* saved_r,
+                                             float* work_v, float* work_r, float* seam_err_v, float* seam_err_r,
+                                             icrl_stream_t stream) {
+    const char* who = "icrl_chain_pair_fwd_seg_f16x2";
+    HpArgs v{}, r{};
+    if (int rc = make_geom(who, N, p0_v, n_calls, full_calls, segments, warmup_v, v.g)) return rc;
+    if (int rc = make_geom(who, N, p0_r, n_calls, full_calls, segments, warmup_r, r.g)) return rc;
+    ICRL_REQUIRE(xproj_v && w_hh_v && xproj_r && w_hh_r && b_hh_r && h_emit_v && h_emit_r && work_v && work_r &&
+                 seam_err_v && seam_err_r, "%s: null pointer", who);
+    ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(xproj_r) && aligned16(w_hh_r) &&
+                 aligned16(b_hh_r) && aligned16(h_emit_v) && aligned16(saved_v) && aligned16(h_emit_r) &&
+                 aligned16(saved_r) && aligned16(work_v) && aligned16(work_r),
+                 "%s: buffers must be 16-byte aligned", who);
+    ICRL_REQUIRE(icrl_chain_f16x2_supported(segments),
+                 "%s: %d segments need more workgroups than the device can hold at once; its workgroups wait for each "
+                 "other and must all be resident", who, segments);
+    hipStream_t st = icrl::as_stream(stream);
+    v.xproj = xproj_v; v.w_hh = w_hh_v; v.b_hh = nullptr; v.saved = saved_v; v.h_emit = h_emit_v;
+    r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = saved_r; r.h_emit = h_emit_r;
+    unsigned* abort_w = nullptr;
+    if (int rc = pair_hp(v, r, work_v, work_r, st, &abort_w, seam_err_v, seam_err_r)) return rc;
+    const int nb = seam_blocks(v.g.K * 2 * H);
+    hipLaunchKernelGGL(seam_check_fwd_pair, dim3(2 * nb), dim3(256), 0, st, v.seam_a, v.seam_b, v.g, seam_err_v, r.seam_a,
+                       r.seam_b, r.g, seam_err_r, abort_w, nb);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
 }
 
 extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* w_hh, int N, int p0, int n_calls, int full_calls,

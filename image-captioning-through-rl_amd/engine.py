@@ -183,6 +183,7 @@ class A2CEngine:
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
                  frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f32x3", late_policy_bptt=True,
+                 chain_arith="f16x2",
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -223,6 +224,11 @@ class A2CEngine:
         # launch's 11.5, but it holds every CU's registers, and inside the A2C step, where the policy network's
         # backward pass shares the CUs with the chain, the step gets slower with it (soak 10.9 -> 12.7 ms)
         self.warm16_backward = bool(warm16_backward)
+        # recurrent products of the two forward chains' persistent launch: "f16x2" = every step on the f16 matrix
+        # instruction, both operands cut into two scaled f16 pieces (float32-level accuracy: 2^-21 per element product;
+        # W_hh in registers, 16-unit tiles), "f32" = the exact float32 instruction (with the 16-bit warm-up part, if on)
+        assert chain_arith in ("f32", "f16x2")
+        self.chain_arith = chain_arith
         # the policy LSTM's backward-through-time as one persistent launch behind the value chain's (see _tail_ok)
         self.late_policy_bptt = bool(late_policy_bptt)
         self._warm16b_off, self._warm16b_penalty = 0, 32
@@ -397,6 +403,8 @@ class A2CEngine:
         return self.last_cheap
 
     def _warm16_active(self, pv, pr):
+        if self.chain_arith == "f16x2" and pv[0] == "segmented" and hip.chain_f16x2_supported(pv[1]):
+            return False   # the f16 launch walks every step alike: no 16-bit part to switch off
         return pv[0] == "segmented" and pr[0] == "segmented" and any(self._cheap_steps(pv[1], pv[2], pr[2]))
 
     def _cheap_steps(self, segments, w_v, w_r):
@@ -1151,6 +1159,14 @@ class A2CEngine:
                                     R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, ws["hv"],
                                     ws["saved"] if backward else None, ws["hr"], ws["work_v"], ws["work_r"],
                                     ws["status"][0:1], persistent=self.persistent and hip.chain_pair_supported(n))
+        elif pair and self.chain_arith == "f16x2" and hip.chain_f16x2_supported(plan[1]):
+            self.last_cheap = (0, 0)
+            self._early_now(ws, n, p0, s, main)
+            hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
+                                   R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
+                                   ws["saved"] if keep else None, ws["hr"], ws["work_v"], ws["work_r"], ws["seam"][0:2],
+                                   ws["seam"][2:4], warmup_r=plan_r[2], full_calls=fc,
+                                   saved_r=ws["saved_r"] if collapsed else None, arith="f16x2")
         elif pair:
             cheap = self._note_cheap(plan, plan_r)
             pair_args = (ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],

@@ -45,6 +45,8 @@ SIGNATURES = {
     "icrl_chain_pair_fwd_seg": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp] * 9),
     "icrl_chain_pair_fwd_seg_warm16": (c_int, [c_vp] * 5 + [c_int] * 11 + [c_vp] * 9),
     "icrl_chain_warm16_supported": (c_int, [c_int]),
+    "icrl_chain_f16x2_supported": (c_int, [c_int]),
+    "icrl_chain_pair_fwd_seg_f16x2": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp] * 9),
     "icrl_chain_bwd_warm16_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_warm16": (c_int, [c_vp] * 3 + [c_int] * 7 + [c_vp] * 4),
     "icrl_chain_pair_replay_check": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
@@ -643,13 +645,18 @@ def chain_warm16_supported(segments):
     return bool(load().icrl_chain_warm16_supported(int(segments)))
 
 
+def chain_f16x2_supported(segments):
+    return bool(load().icrl_chain_f16x2_supported(int(segments)))
+
+
 def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, segments, warmup, h_emit_v,
                        saved_v, h_emit_r, work_v, work_r, seam_err_v, seam_err_r, warmup_r=None, full_calls=0,
-                       saved_r=None, cheap=(0, 0), phase=0):
+                       saved_r=None, cheap=(0, 0), phase=0, arith="f32"):
     """Value LSTM chain and reward GRU chain, every step, in one persistent launch (warmup_r: the
     reward chain's own warm-up length; default: the value chain's).  cheap = (value, reward): the first steps of
     each warm-up that run at 16-bit split precision in a launch of their own (icrl_chain_pair_fwd_seg_warm16);
-    phase 1 queues that launch alone, phase 2 (same arguments) the rest."""
+    phase 1 queues that launch alone, phase 2 (same arguments) the rest.  arith="f16x2": every step of both chains
+    on the f16 matrix instruction at float32-level accuracy (icrl_chain_pair_fwd_seg_f16x2; no cheap part)."""
     _chain_shapes("chain_pair_fwd_seg (value)", n, p0_v, n_calls, 4, xproj=xproj_v, w_hh=w_hh_v, h_emit=h_emit_v,
                   saved=saved_v, slots=6, work=work_v, segments=segments, full_calls=full_calls)
     _chain_shapes("chain_pair_fwd_seg (reward)", n, p0_r, n_calls, 3, xproj=xproj_r, w_hh=w_hh_r, h_emit=h_emit_r,
@@ -658,7 +665,11 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
     steps_v = _seg_steps(n, p0_v, n_calls, full_calls, segments, warmup)
     steps_r = _seg_steps(n, p0_r, n_calls, full_calls, segments, warmup_r)
     positions = chain_positions(n, p0_v, n_calls, full_calls) + chain_positions(n, p0_r, n_calls, full_calls)
-    if phase == 1:    # the 16-bit launch alone: no float32 matrix-instruction work
+    if arith == "f16x2":
+        assert phase == 0 and not (cheap[0] or cheap[1])
+        timed = _Timed("chain_pair_fwd_f16x2", positions, steps=max(steps_v, steps_r),
+                       flops=2.0 * segments * 512 * 512 * (4 * steps_v + 3 * steps_r))
+    elif phase == 1:    # the 16-bit launch alone: no float32 matrix-instruction work
         timed = _Timed("chain_warm16", 0, steps=max(cheap))
     else:
         # float32 matrix-instruction work: the steps that do not run at 16-bit split precision; a phase-2 call
@@ -671,7 +682,9 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
                 n, p0_v, p0_r, n_calls, full_calls, segments, warmup, warmup_r)
         tail = (_ptr(_f32c(h_emit_v)), _ptr(saved_v), _ptr(_f32c(h_emit_r)), _ptr(saved_r), _ptr(_f32c(work_v)),
                 _ptr(_f32c(work_r)), _ptr(seam_err_v), _ptr(seam_err_r), _stream())
-        if cheap[0] or cheap[1]:
+        if arith == "f16x2":
+            rc = load().icrl_chain_pair_fwd_seg_f16x2(*head, *tail)
+        elif cheap[0] or cheap[1]:
             rc = load().icrl_chain_pair_fwd_seg_warm16(*head, int(cheap[0]), int(cheap[1]), int(phase), *tail)
         else:
             assert phase == 0

@@ -363,6 +363,21 @@ int icrl_chain_pair_fwd_seg_warm16(const float* xproj_v, const float* w_hh_v, co
                                    int cheap_v, int cheap_r, int phase, float* h_emit_v, float* saved_v,
                                    float* h_emit_r, float* saved_r, float* work_v, float* work_r,
                                    float* seam_err_v, float* seam_err_r, icrl_stream_t stream);
+/* icrl_chain_pair_fwd_seg (both forward chains of models.py:133, 226, every step, one persistent launch) with the
+ * recurrent products on the f16 matrix instruction at float32-level accuracy: every operand is scaled by a power
+ * of two (h by 2^12, each row of W_hh by the one that brings its largest entry into [2^10, 2^11)) and cut into two
+ * f16 pieces, x s = hi + mid to 2^-22, and a product is hi.hi + hi.mid + mid.hi with float32 sums - what is
+ * dropped is below 2^-21 of each element product, the size of float32's rounding of the 512-term sum.  W_hh stays
+ * in registers for the whole launch, so a step moves only the exchanged h.  Same arguments, outputs, seam errors
+ * and workspaces as icrl_chain_pair_fwd_seg; results agree with it to float32 rounding, not bit for bit.
+ * icrl_chain_f16x2_supported(segments): whether the launch fits the device. */
+int icrl_chain_f16x2_supported(int segments);
+int icrl_chain_pair_fwd_seg_f16x2(const float* xproj_v, const float* w_hh_v, const float* xproj_r,
+                                  const float* w_hh_r, const float* b_hh_r, int N, int p0_v, int p0_r, int n_calls,
+                                  int full_calls, int segments, int warmup_v, int warmup_r, float* h_emit_v,
+                                  float* saved_v, float* h_emit_r, float* saved_r, float* work_v, float* work_r,
+                                  float* seam_err_v, float* seam_err_r, icrl_stream_t stream);
+
 
 /* The check that goes with full_calls < n_calls (no counterpart in the reference, which always replays):
  * for every call s >= full_calls, run the first `steps` positions of the replay that was left out, from the

@@ -801,3 +801,91 @@ def test_f32x3_gemm_rejects_what_it_does_not_do():
     a = torch.zeros(8, 8, device="cuda")
     with pytest.raises(RuntimeError, match="no row gather"):
         hip.gemm(a, a, torch.zeros(8, 8, device="cuda"), bias=a[0], bias2=a[0], dtype="f32x3")
+
+
+@pytest.mark.parametrize("n,t_steps", [(512, 19), (48, 5), (7, 3)])
+def test_persistent_policy_lstm_bptt_against_the_launches_issued_one_by_one(n, t_steps):
+    """icrl_policy_lstm_bptt_persist (the backward chain kernel walking N per-row chains with a gradient injected at
+    every step, one launch) against icrl_policy_lstm_bptt (cell backward + product per step): the same gate gradients
+    and initial-state gradient to float32 rounding (different summation orders), twice in a row."""
+    assert hip.chain_pair_supported(n)
+    rs = np.random.RandomState(11)
+    w_hh = dev(rnd(rs, 4 * H, H, scale=H ** -0.5))
+    xw = rnd(rs, t_steps, n, 4 * H)
+    c_all = torch.zeros(t_steps + 1, n, H, device="cuda")     # the policy network starts from c = 0
+    h_all = torch.zeros(t_steps + 1, n, H, device="cuda")
+    h_all[0] = dev(rnd(rs, n, H))
+    gates = torch.empty(t_steps, n, 4 * H, device="cuda")
+    for k in range(t_steps):
+        gates[k] = dev(xw[k])
+        hip.gemm(h_all[k], w_hh, gates[k], accumulate=True)
+        hip.lstm_cell_fwd(gates[k], c_all[k], c_all[k + 1], h_all[k + 1])
+    d_out = dev(rnd(rs, t_steps, n, H, scale=0.1))
+    scratch = torch.empty(16 * n * H, device="cuda")
+    d_h, dgp = d_out.clone(), torch.empty(t_steps, n, 4 * H, device="cuda")
+    dc0, dc1, dh0 = (torch.empty(n, H, device="cuda") for _ in range(3))
+    hip.policy_lstm_bptt(gates, c_all, d_h, w_hh, dgp, dc0, dc1, dh0, scratch, shared=True)
+    work = torch.zeros(hip.chain_seg_workspace_floats(n), device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        dgp2, dh02 = torch.full_like(dgp, float("nan")), torch.full_like(dh0, float("nan"))
+        hip.policy_lstm_bptt_persist(gates, c_all, d_out, w_hh, dgp2, dh02, work, status)
+        torch.cuda.synchronize()
+        assert int(status[0]) == 0
+        scale = dgp.abs().max().item()
+        assert (dgp2 - dgp).abs().max().item() <= 2e-5 * scale
+        assert (dh02 - dh0).abs().max().item() <= 2e-5 * dh0.abs().max().item()
+
+
+@pytest.mark.parametrize("n,p0,calls,segs,warm", [(64, 1, 19, 32, 64), (48, 2, 12, 96, 16), (512, 1, 19, 256, 96)])
+def test_forward_chain_pair_on_the_f16_matrix_instruction(n, p0, calls, segs, warm):
+    """icrl_chain_pair_fwd_seg_f16x2 (operands as two scaled f16 pieces, W_hh in registers) against the exact-float32
+    persistent pair launch on the same inputs: every kept activation, emitted h and both seam errors to float32
+    rounding level (1e-6 of the activations' unit scale; a recurrence carries a rounding difference along until it is
+    forgotten, so not bit for bit), twice in a row; and closer to a float64 evaluation of the same segment than 4e-6."""
+    assert hip.chain_pair_supported(segs) and hip.chain_f16x2_supported(segs)
+    rs = np.random.RandomState(segs + 3)
+    cols = p0 + calls
+    pos_v = n * sum(p0 + s for s in range(calls))
+    pos_r = n * sum(p0 + 1 + s for s in range(calls))
+    xv, wv = _chain_inputs(rs, n, cols, 4)
+    xg, wg = _chain_inputs(rs, n, cols + 1, 3)
+    wv[:64] *= 6.0            # rows of W_hh of very different sizes: every row has a scale of its own
+    wg[5] = 0.0               # an all-zero row
+    xv_d, wv_d, xg_d, wg_d = dev(xv), dev(wv), dev(xg), dev(wg)
+    bg = dev(rnd(rs, 3 * H, scale=0.1))
+    work_v, err_v = _seg_ws(segs)
+    work_r, err_r = _seg_ws(segs)
+    outs = {}
+    for arith in ("f32", "f16x2", "f16x2"):
+        h_p, saved_p = torch.zeros(calls, n, H, device="cuda"), torch.full((pos_v, 6, H), 7.0, device="cuda")
+        g_p, gsaved_p = torch.zeros(calls, n, H, device="cuda"), torch.full((pos_r, 5, H), 7.0, device="cuda")
+        hip.chain_pair_fwd_seg(xv_d, wv_d, xg_d, wg_d, bg, n, p0, p0 + 1, calls, segs, warm, h_p, saved_p, g_p, work_v,
+                               work_r, err_v, err_r, warmup_r=warm + 5, saved_r=gsaved_p, arith=arith)
+        torch.cuda.synchronize()
+        got = (h_p, saved_p, g_p, gsaved_p, err_v[0].item(), err_r[0].item())
+        if arith in outs:     # the second f16 call: the same bits as the first
+            assert all(torch.equal(a, b) for a, b in zip(got[:4], outs[arith][:4])) and got[4:] == outs[arith][4:]
+        outs[arith] = got
+    ref, new = outs["f32"], outs["f16x2"]
+    assert not (new[1] == 7.0).any() and not (new[3] == 7.0).any(), "every position's activations are written"
+    for a, b in zip(new[:4], ref[:4]):
+        assert (a - b).abs().max().item() <= 2e-6, (a - b).abs().max().item()
+    assert abs(new[4] - ref[4]) <= 2e-6 and abs(new[5] - ref[5]) <= 2e-6
+    # float64 walk of the first positions of the LSTM chain (segment 0 starts from the true zero state)
+    steps = min(pos_v, 40)
+    h = torch.zeros(H, dtype=torch.float64)
+    c = torch.zeros(H, dtype=torch.float64)
+    w64 = torch.from_numpy(wv).double()
+    worst_new = worst_ref = 0.0
+    for pos in range(steps):
+        col, row = (pos // n), pos % n       # call 0 walks columns 0 .. p0-1 row by row
+        if col >= p0:
+            break
+        g = torch.from_numpy(xv[col * n + row]).double() + w64 @ h
+        i, f, gg, o = g.chunk(4)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        worst_new = max(worst_new, (new[1][pos, 5].cpu().double() - h).abs().max().item())
+        worst_ref = max(worst_ref, (ref[1][pos, 5].cpu().double() - h).abs().max().item())
+    assert worst_new <= 4e-6 and worst_new <= 4.0 * worst_ref + 1e-6, (worst_new, worst_ref)

@@ -140,7 +140,8 @@ def test_engine_uses_warm16_from_128_warm_up_steps_and_gets_the_same_minibatch()
     args = (torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :1]).cuda(), 19)
     out = {}
     for warm16 in (True, False, "backward too"):
-        engine = trainers.build_engine(a2c, nets[2], first_warmup=128, warm16=bool(warm16),
+        # the 16-bit warm-up part belongs to the float32 launch (the default f16 launch walks every step alike)
+        engine = trainers.build_engine(a2c, nets[2], first_warmup=128, warm16=bool(warm16), chain_arith="f32",
                                        warm16_backward=warm16 == "backward too")
         res = engine.step(*args, uniforms=u).check()
         torch.cuda.synchronize()
@@ -149,7 +150,14 @@ def test_engine_uses_warm16_from_128_warm_up_steps_and_gets_the_same_minibatch()
         assert (engine.last_cheap_bwd > 0) == (warm16 == "backward too")   # the backward launch only when asked for
         out[warm16] = (res.tokens.clone(), res.values.clone(), res.rewards.clone(),
                        {k: p.grad.clone() for k, p in a2c.named_parameters()})
-    for variant in (True, "backward too"):
+    # and the default engine (both forward chains on the f16 matrix instruction, every step)
+    engine = trainers.build_engine(a2c, nets[2], first_warmup=128)
+    res = engine.step(*args, uniforms=u).check()
+    torch.cuda.synchronize()
+    assert engine.chain_arith == "f16x2" and engine.last_cheap == (0, 0) and engine.fallbacks == 0
+    out["f16x2"] = (res.tokens.clone(), res.values.clone(), res.rewards.clone(),
+                    {k: p.grad.clone() for k, p in a2c.named_parameters()})
+    for variant in (True, "backward too", "f16x2"):
         assert torch.equal(out[variant][0], out[False][0])
         for a, b in zip(out[variant][1:3], out[False][1:3]):
             assert float((a - b).abs().max()) <= 1e-5
