@@ -202,6 +202,8 @@ def main():
                          "step on the networks they produce (trained-regime run, reported under its own workload name)")
     ap.add_argument("--chain-arith", default=None, choices=("f32", "f16x2"),
                     help="recurrent products of the forward chains' persistent launch (default: the engine's)")
+    ap.add_argument("--max-streams", type=int, default=None, choices=(3, 4),
+                    help="streams the engine uses, the caller's included (default: the engine's)")
     ap.add_argument("--no-late-policy-bptt", action="store_true",
                     help="the policy LSTM's BPTT as 3 T launches on the side stream beside the value chain's (the "
                          "schedule before the persistent policy BPTT launch)")
@@ -247,6 +249,8 @@ def main():
     if args.grad_products is not None:
         engine_opts["grad_products"] = args.grad_products
     engine = trainers.build_engine(a2c, rew, **engine_opts)
+    if args.max_streams is not None:
+        engine.max_streams = args.max_streams
     feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, rank)  # a different shard per rank
     feats_d = torch.from_numpy(feats).to(dev)
     prefix_d = torch.from_numpy(caps[:, :1]).to(dev)
@@ -255,13 +259,17 @@ def main():
         np.random.RandomState(1000 + rank).random_sample((total_steps, steps_per_rollout * n))).to(dev)
 
     # N > 1: the policy network's gradients cross the links beside the value chain's backward pass
-    averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."))
+    averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."), stream=engine.side_stream())
     engine.on_policy_grads = averager.start_early
+
+    sync_each = os.environ.get("ICRL_BENCH_SYNC_EACH") == "1"   # diagnosis: the device drained after every minibatch
 
     def one_step(i):
         res = engine.step(feats_d, prefix_d, steps_per_rollout, uniforms=uniforms[i])
         averager.finish()
         opt.step()
+        if sync_each:
+            torch.cuda.synchronize()
         return res.check()  # reads the status word back: one host sync per step, as .item() in the reference loop
 
     for i in range(args.warmup):

@@ -1922,6 +1922,224 @@ __global__ __launch_bounds__(256, 1) void seg_warm_bwd(WarmBwdArgs a, unsigned* 
 #undef WB_LOAD
 }
 
+
+// ------------------------------------------------------------------ LSTM backward chain: owner computes, partial sums exchanged, f16 matrix instruction
+// dh(p) = dgates(p+1) . W_hh sums over all 2048 gate rows, and the gate gradients of a position are produced 128 at
+// a time by the workgroup that owns their 32 units.  seg_bwd_persist gathers: every workgroup of a row group pulls
+// the group's whole 32 x 2048 dgates panel (256 KB) each step.  Here a workgroup multiplies only what it produced
+// itself: partial[32 segments][512 units] = own dgates [32][128] . W_hh[its 128 gate rows][512], and hands each of the
+// 16 workgroups of its row group the 32 x 32 tile that belongs to that one's units; a workgroup then adds up the 16
+// tiles it was sent.  64 KB out and 64 KB in per workgroup and step, and the dgates never leave the workgroup - so
+// they can be cut into f16 pieces with a scale of their own per segment row (the largest of the row's 128 values
+// brought into [2^13, 2^14); gradients span too many binades for one scale, and the exchanged partial sums are
+// float32, descaled exactly).  W_hh's slice is cut into two f16 pieces once (one power-of-two scale per wave) and
+// stays in registers; products as in hp_chain: hi.hi + hi.mid + mid.hi, float32 sums, 2^-21 per element product.
+// 512 threads: the eight waves split the 512 output units; threads 0..255 each own one (segment row, 4 units) item
+// of the cell's backward pass.  Hand-off: write-through stores, drained, one flag per workgroup and step, sc1 loads.
+constexpr int RS_LDB = 128 + 8;     // f16 per LDS row of a dgates plane: the workgroup's 128 gate rows, padded
+
+struct RsArgs {
+    const float* w_hh; const float* d_emit;
+    const float* saved; const float* cc;   // activations of the forward pass, as in BwdArgs
+    int gate_stride, c_stride;
+    float* part;              // [2][row groups][16 receivers][16 senders][32 rows][32 units] partial products
+    float* dc; float* dgv; float* seam_a; float* dh_fin;
+    unsigned* flags;          // [row groups][16]
+    Geom g;
+};
+
+__global__ __launch_bounds__(512, 1) void seg_bwd_rs(RsArgs a, unsigned* abort_w) {
+    __shared__ __attribute__((aligned(16))) _Float16 planes[2 * 32 * RS_LDB];   // [hi | mid][segment row][own gate row]
+    __shared__ float row_descale[32];
+    __builtin_amdgcn_s_setprio(3);
+    const Geom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int bx = blockIdx.x % 16, by = blockIdx.x / 16;
+    const int groups = gridDim.x / 16;
+    const int row0 = by * 32, u0 = bx * 32;
+    constexpr int TILE_B = 32 * 32 * 4;                                 // bytes of one 32 x 32 partial tile
+    const int parity_b = groups * 16 * 16 * TILE_B;                     // bytes of one parity of the exchange buffer
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 2 * parity_b, 0x00020000);
+
+    // A operand of lane (output unit l15 of tile mt, k group kg) at k step ks: W_hh[gate ks, unit u0 + 8 kg + 0..7][64 w + 16 mt + l15]
+    hf16x8 wa[2][4][4];
+    float descale_w;
+    {
+        const float* wcol = a.w_hh + (int64_t)(u0 + 8 * kg) * H + 64 * w + l15;
+        float top = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) top = fmaxf(top, fabsf(wcol[((int64_t)ks * H + e) * H + 16 * mt]));
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) top = fmaxf(top, __shfl_xor(top, sh));
+        int ex = 0;
+        if (top > 0.f && top < INFINITY) frexpf(top, &ex);
+        ex = max(-100, min(100, ex));
+        const float scale = ldexpf(1.f, 11 - ex);       // the wave's largest entry in [2^10, 2^11)
+        descale_w = ldexpf(1.f, ex - 11);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 hi, mid;
+                    split2h(wcol[((int64_t)ks * H + e) * H + 16 * mt] * scale, hi, mid);
+                    wa[0][mt][ks][e] = hi;
+                    wa[1][mt][ks][e] = mid;
+                }
+    }
+
+    // threads 0..255: the epilogue item (segment row j, units u..u+3) and its carried dc
+    const bool item = tid < 256;
+    const int rr = (tid >> 3) & 31, quad = tid & 7;
+    const int j = row0 + rr, u = u0 + 4 * quad;
+    const bool have_row = item && j < g.K;
+    float4 dcv = zero4();
+    int ps = 0, pt = 0, pi = 0;
+    const int in_voff = (rr * 32 + 4 * quad) * 4;                       // this item's place in a received tile
+    const int in_soff = ((by * 16 + bx) * 16) * TILE_B;                 // + sender * TILE_B + parity
+    // where this lane's products go: receiver 2 w + mt / 2, rows 16 nt + l15, units 16 (mt % 2) + 4 kg .. + 3
+    const int out_voff = (l15 * 32 + 4 * kg) * 4;
+
+    const int steps = g.W + g.Ls;
+    for (int mp = 0; mp <= steps; ++mp) {
+        const bool final = mp == steps;
+        const int cur = mp & 1;                  // this step writes parity cur and reads parity cur ^ 1
+        const int qs = g.Ls + g.W - 1 - mp;      // step within the segment: >= Ls during the warm-up
+        const int64_t pos = seg_pos(g, j, qs);
+        const bool live = have_row && !final && pos < g.total && seg_pos(g, j, 0) < g.total;
+        float4 gi = zero4(), gf = zero4(), gg = zero4(), go = zero4(), cc = zero4(), cp = zero4(), de = zero4();
+        if (live) {
+            locate_fast(g, (int)pos, ps, pt, pi);
+            const float* sp = a.saved + pos * a.gate_stride + u;
+            gi = ld4(sp); gf = ld4(sp + H); gg = ld4(sp + 2 * H); go = ld4(sp + 3 * H);
+            cc = ld4(a.cc + pos * a.c_stride + u);
+            if (pos >= g.stride) cp = ld4(a.cc + (pos - g.stride) * a.c_stride + u);
+            if (pt == g.p0 + ps - 1) de = ld4(a.d_emit + ((int64_t)ps * g.n + pi) * H + u);
+        }
+
+        float4 dh = zero4();
+        if (mp > 0) {
+            if (w == 0) wait_row_group(a.flags + by * 16, (unsigned)mp, abort_w, lane);
+            __syncthreads();
+            if (item) {   // the 16 tiles this workgroup was sent, added up in a fixed order
+                v4u raw[16];
+                const int so = (cur ^ 1) * parity_b + in_soff;
+#pragma unroll
+                for (int sd = 0; sd < 16; ++sd) raw[sd] = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, so + sd * TILE_B, SC1);
+                float4 s0 = add4(add4(as_f4(raw[0]), as_f4(raw[1])), add4(as_f4(raw[2]), as_f4(raw[3])));
+                float4 s1 = add4(add4(as_f4(raw[4]), as_f4(raw[5])), add4(as_f4(raw[6]), as_f4(raw[7])));
+                float4 s2 = add4(add4(as_f4(raw[8]), as_f4(raw[9])), add4(as_f4(raw[10]), as_f4(raw[11])));
+                float4 s3 = add4(add4(as_f4(raw[12]), as_f4(raw[13])), add4(as_f4(raw[14]), as_f4(raw[15])));
+                dh = add4(add4(s0, s1), add4(s2, s3));
+            }
+        }
+        float4 d_i = zero4(), d_f = zero4(), d_g = zero4(), d_o = zero4(), dcn = zero4();
+        if (have_row) {
+            if (final) {
+                st4(a.dh_fin + (int64_t)j * H + u, dh);
+                st4(a.dc + (int64_t)j * H + u, dcv);
+            } else {
+                if (qs == g.Ls - 1) {  // state entering the segment's last own position
+                    st4(a.seam_a + (int64_t)j * 2 * H + u, dh);
+                    st4(a.seam_a + (int64_t)j * 2 * H + H + u, dcv);
+                }
+                if (live) {
+                    dh = add4(dh, de);
+                    LSTM_BWD4(dh, dcv, gi, gf, gg, go, cc, cp, d_i, d_f, d_g, d_o, dcn)
+                    if (qs < g.Ls) {
+                        float* dp = a.dgv + pos * (4 * H) + u;
+                        st4(dp, d_i); st4(dp + H, d_f); st4(dp + 2 * H, d_g); st4(dp + 3 * H, d_o);
+                    }
+                }
+                dcv = dcn;
+            }
+        }
+        if (final) break;
+
+        // this step's own dgates, scaled per segment row and cut in two, into LDS as the B operand
+        if (item) {
+            float top = fmaxf(fmaxf(fmaxf(fabsf(d_i.x), fabsf(d_i.y)), fmaxf(fabsf(d_i.z), fabsf(d_i.w))),
+                              fmaxf(fmaxf(fabsf(d_f.x), fabsf(d_f.y)), fmaxf(fabsf(d_f.z), fabsf(d_f.w))));
+            top = fmaxf(top, fmaxf(fmaxf(fmaxf(fabsf(d_g.x), fabsf(d_g.y)), fmaxf(fabsf(d_g.z), fabsf(d_g.w))),
+                                   fmaxf(fmaxf(fabsf(d_o.x), fabsf(d_o.y)), fmaxf(fabsf(d_o.z), fabsf(d_o.w)))));
+            top = fmaxf(top, __shfl_xor(top, 1));     // the eight lanes of a segment row are neighbours
+            top = fmaxf(top, __shfl_xor(top, 2));
+            top = fmaxf(top, __shfl_xor(top, 4));
+            int ex = 0;
+            if (top > 0.f && top < INFINITY) frexpf(top, &ex);
+            ex = max(-110, min(110, ex));
+            const float scale = ldexpf(1.f, 14 - ex);   // the row's largest value in [2^13, 2^14)
+            if (quad == 0) row_descale[rr] = ldexpf(1.f, ex - 14);
+            const float4 dv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                hf16x4 hi, mid;
+                _Float16 h_, m_;
+                split2h(dv[gq].x * scale, h_, m_); hi[0] = h_; mid[0] = m_;
+                split2h(dv[gq].y * scale, h_, m_); hi[1] = h_; mid[1] = m_;
+                split2h(dv[gq].z * scale, h_, m_); hi[2] = h_; mid[2] = m_;
+                split2h(dv[gq].w * scale, h_, m_); hi[3] = h_; mid[3] = m_;
+                *reinterpret_cast<hf16x4*>(planes + rr * RS_LDB + 32 * gq + 4 * quad) = hi;
+                *reinterpret_cast<hf16x4*>(planes + (32 + rr) * RS_LDB + 32 * gq + 4 * quad) = mid;
+            }
+        }
+        __syncthreads();
+
+        // partial[unit 64 w + 16 mt + ..][segment row 16 nt + ..] over the workgroup's 128 gate rows
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            hf16x8 b_hi[2], b_mid[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const _Float16* br = planes + (16 * nt + l15) * RS_LDB + 32 * ks + 8 * kg;
+                b_hi[nt] = *reinterpret_cast<const hf16x8*>(br);
+                b_mid[nt] = *reinterpret_cast<const hf16x8*>(br + 32 * RS_LDB);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][mt][ks], b_hi[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[0][mt][ks], b_mid[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[1][mt][ks], b_hi[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        // accumulator register r of lane (l15, kg) is [unit 4 kg + r of tile mt][segment row l15 of tile nt]:
+        // four consecutive units of one row, 16 bytes of the tile the receiver 2 w + mt / 2 reads
+        {
+            const float ds[2] = {descale_w * row_descale[l15], descale_w * row_descale[16 + l15]};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int so = cur * parity_b + ((by * 16 + 2 * w + (mt >> 1)) * 16 + bx) * TILE_B + (mt & 1) * 64;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float4 v = make_float4(acc[mt][nt][0] * ds[nt], acc[mt][nt][1] * ds[nt], acc[mt][nt][2] * ds[nt],
+                                                 acc[mt][nt][3] * ds[nt]);
+                    __builtin_amdgcn_raw_buffer_store_b128(as_u4(v), rs, out_voff + nt * 16 * 32 * 4, so, SC1);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores ...
+        __syncthreads();                                    // ... before ONE lane signals for all of them
+        if (tid == 0)
+            __hip_atomic_store((gu32*)(a.flags + by * 16 + bx), (unsigned)(mp + 1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // after the seam checks: a launch that gave up waiting must not pass them
 __global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* seam_r) {
     if (*abort_w != 0) { *seam_v = INFINITY; *seam_r = INFINITY; }
@@ -2115,6 +2333,33 @@ int bwd_persist(BwdArgs& a, float* work, hipStream_t st, unsigned** abort_out, i
     return ICRL_OK;
 }
 
+
+// floats of the owner-computes backward launch's workspace: the exchanged partial tiles (two parities), then dc,
+// seam_a, dh_fin per segment, then the polled words
+int64_t bwd_rs_floats(int K) {
+    const int64_t groups = (K + 31) / 32;
+    return groups * (2 * 16 * 16 * 1024) + groups * 32 * (4 * H) + 1024;
+}
+
+int bwd_rs(RsArgs& a, float* work, hipStream_t st, unsigned** abort_out, float* seam_err, float* dh_out = nullptr) {
+    const int K = a.g.K;
+    const int64_t groups = (K + 31) / 32, rows = groups * 32;
+    if (a.cc == nullptr) {   // the chains' own records {i, f, g, o, c, h}
+        a.cc = a.saved + 4 * H;
+        a.gate_stride = a.c_stride = 6 * H;
+    }
+    a.part = work;
+    float* tail = work + groups * (2 * 16 * 16 * 1024);
+    a.dc = tail; a.seam_a = tail + rows * H; a.dh_fin = dh_out ? dh_out : tail + 3 * rows * H;
+    unsigned* words = reinterpret_cast<unsigned*>(tail + 4 * rows * H);
+    a.flags = words;
+    *abort_out = words + groups * 16;
+    ICRL_REQUIRE(groups * 16 + 4 <= 1024, "owner-computes backward launch: too many row groups");
+    ZeroArgs z{{reinterpret_cast<float*>(words), seam_err, nullptr, nullptr, nullptr}, {1024, seam_err ? 2 : 0, 0, 0, 0}};
+    hipLaunchKernelGGL(zero_regions, dim3(8), dim3(256), 0, st, z);
+    hipLaunchKernelGGL(seg_bwd_rs, dim3(16 * (unsigned)groups), dim3(512), 0, st, a, *abort_out);
+    return ICRL_OK;
+}
 }  // namespace
 
 extern "C" int64_t icrl_chain_seg_workspace_floats(int segments) { return (int64_t)segments * 16 * H; }
@@ -2694,6 +2939,72 @@ extern "C" int icrl_policy_lstm_bptt_persist(const float* gates_act, const float
     ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
     unsigned* abort_w = nullptr;
     if (int rc = bwd_persist(a, work, st, &abort_w, 0, nullptr, dh0)) return rc;
+    hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+// ------------------------------------------------------------------ backward chain, owner-computes launch (seg_bwd_rs)
+extern "C" int64_t icrl_chain_bwd_f16x2_workspace_floats(int segments) { return segments > 0 ? bwd_rs_floats(segments) : 0; }
+
+extern "C" int icrl_chain_bwd_f16x2_supported(int segments) {
+    // all 16 x ceil(segments / 32) workgroups (512 threads each) must be resident at once
+    static int cus = -1, per_cu = 0;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seg_bwd_rs, 512, 0) != hipSuccess) return 0;
+        cus = n;
+    }
+    if (segments < 1) return 0;
+    return 16 * ((segments + 31) / 32) <= cus * per_cu ? 1 : 0;
+}
+
+extern "C" int icrl_lstm_chain_bwd_seg_f16x2(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                                             int n_calls, int full_calls, int segments, int warmup, float* dgates,
+                                             float* work, float* seam_err, icrl_stream_t stream) {
+    const char* who = "icrl_lstm_chain_bwd_seg_f16x2";
+    RsArgs a{};
+    if (int rc = make_geom(who, N, p0, n_calls, full_calls, segments, warmup, a.g)) return rc;
+    ICRL_REQUIRE(w_hh && saved && d_emit && dgates && work && seam_err, "%s: null pointer", who);
+    ICRL_REQUIRE(aligned16(w_hh) && aligned16(saved) && aligned16(d_emit) && aligned16(dgates) && aligned16(work),
+                 "%s: buffers must be 16-byte aligned", who);
+    ICRL_REQUIRE(icrl_chain_bwd_f16x2_supported(segments),
+                 "%s: %d segments need more workgroups than the device can hold at once; its workgroups wait for each "
+                 "other and must all be resident", who, segments);
+    hipStream_t st = icrl::as_stream(stream);
+    a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgv = dgates;
+    unsigned* abort_w = nullptr;
+    if (int rc = bwd_rs(a, work, st, &abort_w, seam_err)) return rc;
+    hipLaunchKernelGGL(seam_check_bwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.dh_fin, a.dc,
+                       a.g, seam_err, seam_err + 1, (const unsigned*)abort_w);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_policy_lstm_bptt_f16x2(const float* gates_act, const float* c_all, const float* d_h,
+                                           const float* w_hh, int N, int T, float* dgates, float* dh0, float* work,
+                                           int* status, icrl_stream_t stream) {
+    const char* who = "icrl_policy_lstm_bptt_f16x2";
+    ICRL_REQUIRE(gates_act && c_all && d_h && w_hh && dgates && dh0 && work && status, "%s: null pointer", who);
+    ICRL_REQUIRE(N > 0 && N <= 4096 && T > 0 && (int64_t)N * T < ((int64_t)1 << 30),
+                 "%s: need 0 < N <= 4096, T > 0, N T < 2^30", who);
+    ICRL_REQUIRE(aligned16(gates_act) && aligned16(c_all) && aligned16(d_h) && aligned16(w_hh) && aligned16(dgates) &&
+                 aligned16(dh0) && aligned16(work), "%s: buffers must be 16-byte aligned", who);
+    ICRL_REQUIRE(icrl_chain_bwd_f16x2_supported(N), "%s: %d rows need more workgroups than the device can hold at once",
+                 who, N);
+    RsArgs a{};
+    Geom& g = a.g;
+    g.n = N; g.p0 = 1; g.n_calls = T; g.fc = 1; g.c0 = 1;
+    g.total = (int64_t)N * T; g.K = N; g.Ls = T; g.W = 0; g.stride = N;
+    a.w_hh = w_hh; a.d_emit = d_h; a.dgv = dgates;
+    a.saved = gates_act; a.gate_stride = 4 * H;
+    a.cc = c_all + (int64_t)N * H; a.c_stride = H;
+    hipStream_t st = icrl::as_stream(stream);
+    ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+    unsigned* abort_w = nullptr;
+    if (int rc = bwd_rs(a, work, st, &abort_w, nullptr, dh0)) return rc;
     hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;

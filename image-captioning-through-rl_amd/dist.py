@@ -82,11 +82,14 @@ class GradientAverager:
     caller knows it is complete (start_early), the rest in finish().  Every rank must make the same
     calls in the same order, once per step each."""
 
-    def __init__(self, flat_grad, early_span):
+    def __init__(self, flat_grad, early_span, stream=None):
+        """stream: the CUDA stream the early collective is queued on (e.g. A2CEngine.side_stream(), where the early
+        range is completed); None: a stream of this object's own.  HIP multiplexes a process's streams onto four
+        hardware queues, so every further stream may end up sharing a queue with one that should run beside it."""
         self.flat_grad = flat_grad
         self.lo, self.hi = early_span
         assert 0 <= self.lo < self.hi <= flat_grad.numel()
-        self._work, self._stream = None, None
+        self._work, self._stream = None, stream
 
     def start_early(self, ready_event=None):
         """Start averaging flat_grad[lo:hi].  ready_event (CUDA): the event after which that range is

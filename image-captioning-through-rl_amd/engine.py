@@ -104,8 +104,12 @@ def _runs_beside(main, cand, cycles=4000000):
         t1.synchronize()
         return t0.elapsed_time(t1)
 
-    serial = spin_pair(None)
-    return spin_pair(cand) < 0.75 * serial
+    # the first timing in a process comes out up to a third too long (4.5 ms for two 1.7 ms spins), which is exactly
+    # what makes a candidate that shares main's queue look as if it overlapped: one untimed pass, then the shorter
+    # of two measurements each
+    spin_pair(None)
+    serial = min(spin_pair(None), spin_pair(None))
+    return min(spin_pair(cand), spin_pair(cand)) < 0.75 * serial
 
 
 class _WarmupLadder:
@@ -224,7 +228,8 @@ class A2CEngine:
         # launch's 11.5, but it holds every CU's registers, and inside the A2C step, where the policy network's
         # backward pass shares the CUs with the chain, the step gets slower with it (soak 10.9 -> 12.7 ms)
         self.warm16_backward = bool(warm16_backward)
-        # recurrent products of the two forward chains' persistent launch: "f16x2" = every step on the f16 matrix
+        # recurrent products of the persistent chain launches (both forward chains, the value chain's BPTT, the policy
+        # LSTM's BPTT): "f16x2" = every step on the f16 matrix
         # instruction, both operands cut into two scaled f16 pieces (float32-level accuracy: 2^-21 per element product;
         # W_hh in registers, 16-unit tiles), "f32" = the exact float32 instruction (with the 16-bit warm-up part, if on)
         assert chain_arith in ("f32", "f16x2")
@@ -245,6 +250,10 @@ class A2CEngine:
         # their all-reduce there, beside the value chain's BPTT
         self.on_policy_grads = None
         self._ev_policy = None
+        # streams the engine uses, the caller's included: 3 (main, side, third), or 4 with a stream of its own for the
+        # replay check (see _replay_stream); side_stream() hands the side stream to a caller that wants its
+        # collective queued there instead of on yet another stream
+        self.max_streams = 3
         # every chain starts at the first rung of at least first_warmup steps (freshly initialised networks
         # pass there); shorter rungs are reached only by probing down
         start = next((i for i, w in enumerate(self.warmups) if w >= first_warmup), len(self.warmups) - 1)
@@ -471,6 +480,10 @@ class A2CEngine:
         plan = lambda i: ("segmented", k, self.warmups[i]) if i < last else ("exact",)
         return fc, plan(fv), plan(fr), plan(bi)
 
+    def _bwd_f16x2(self, rows):
+        """Whether a backward chain over `rows` segments (or rows) runs as the owner-computes f16 launch."""
+        return self.chain_arith == "f16x2" and self.persistent and hip.chain_bwd_f16x2_supported(rows)
+
     def _tail_ok(self, n, pv, pr, pb):
         """Whether this attempt runs the backward pass in the order value chain BPTT -> policy LSTM BPTT (both
         persistent launches on the main stream) -> weight gradients, with everything of the policy network's
@@ -527,6 +540,11 @@ class A2CEngine:
             self._side = self._stream_beside([torch.cuda.current_stream()])
         return self._side
 
+    def side_stream(self):
+        """The engine's second stream (None when it runs everything on the caller's): the policy network's gradients
+        are completed there, so a collective on them that is queued on it needs no stream of its own."""
+        return self._side_stream() if self.concurrent else None
+
     def _replay_stream(self):
         """A fourth stream for the replay check, a persistent launch of 1.5 ms that would otherwise hold the third
         stream's queue while the vocabulary gradients wait behind it (they then start 1.4 ms earlier, beside the
@@ -534,8 +552,16 @@ class A2CEngine:
         Only if a stream is found that really runs beside the other three (HIP has four hardware queues by
         default, and other libraries' streams share them); the third stream otherwise."""
         if self._replay is None:
-            others = [torch.cuda.current_stream(), self._side_stream(), self._check_stream()]
-            self._replay = self._stream_beside(others, strict=True) or self._check_stream()
+            if self.max_streams < 4:
+                # on the side stream, which is idle between the reward head and the vocabulary gradients: those then
+                # start behind the check, 1.5 ms into the value chain's BPTT instead of with it, and the BPTT - which
+                # every product beside it slows down - runs 1.8 ms instead of 2.4 (6.7-6.8 ms per step against 7.2
+                # with a stream of the check's own).  It also leaves a hardware queue (HIP gives a process four) to
+                # the streams of a process group
+                self._replay = self._side_stream()
+            else:
+                others = [torch.cuda.current_stream(), self._side_stream(), self._check_stream()]
+                self._replay = self._stream_beside(others, strict=True) or self._check_stream()
         return self._replay
 
     def _check_stream(self):
@@ -1315,6 +1341,14 @@ class A2CEngine:
             hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
                                     ws["work_v"], ws["status"][2:3],
                                     persistent=self.persistent and hip.chain_pair_supported(n))
+        elif plan[0] == "segmented" and self._bwd_f16x2(plan[1]):
+            # owner-computes launch on the f16 matrix instruction (a workspace of its own: the exchanged partial tiles)
+            self.last_cheap_bwd = 0
+            key = "work_b%d" % plan[1]
+            if key not in ws:
+                ws[key] = torch.empty(hip.chain_bwd_f16x2_workspace_floats(plan[1]), dtype=torch.float32, device=self.device)
+            hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
+                                   dgv, ws[key], ws["seam"][4:6], full_calls=fc, arith="f16x2")
         elif plan[0] == "segmented":
             self.last_cheap_bwd = self._cheap_bwd(plan)
             hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
@@ -1335,10 +1369,12 @@ class A2CEngine:
             ev_dhall, ev_vocab = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
             # the policy LSTM's backward-through-time: one persistent launch, right behind the value chain's
             main.wait_event(ev_dhall)
+            arith = "f16x2" if self._bwd_f16x2(n) else "f32"
             if "work_p" not in ws:
-                ws["work_p"] = torch.empty(hip.chain_seg_workspace_floats(n), dtype=torch.float32, device=self.device)
+                floats = max(hip.chain_seg_workspace_floats(n), hip.chain_bwd_f16x2_workspace_floats(n))
+                ws["work_p"] = torch.empty(floats, dtype=torch.float32, device=self.device)
             hip.policy_lstm_bptt_persist(ws["gates"], ws["Cbuf"], ws["dHall"], self.P["lstm.weight_hh_l0"], ws["dgp"],
-                                         ws["dh0"], ws["work_p"], ws["status"][3:4])
+                                         ws["dh0"], ws["work_p"], ws["status"][3:4], arith=arith)
             self._mark("policy_bptt_done")
             ev_pbptt = torch.cuda.Event()
             ev_pbptt.record(main)

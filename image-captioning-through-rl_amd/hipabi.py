@@ -68,6 +68,10 @@ SIGNATURES = {
     "icrl_lstm_cell_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "icrl_policy_lstm_bptt": (c_int, [c_vp] * 9 + [c_i64] + [c_int] * 5 + [c_vp]),
     "icrl_policy_lstm_bptt_persist": (c_int, [c_vp] * 4 + [c_int] * 2 + [c_vp] * 5),
+    "icrl_policy_lstm_bptt_f16x2": (c_int, [c_vp] * 4 + [c_int] * 2 + [c_vp] * 5),
+    "icrl_chain_bwd_f16x2_workspace_floats": (c_i64, [c_int]),
+    "icrl_chain_bwd_f16x2_supported": (c_int, [c_int]),
+    "icrl_lstm_chain_bwd_seg_f16x2": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 4),
     "icrl_policy_lstm_step": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
                                       c_vp]),
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
@@ -745,11 +749,22 @@ def chain_bwd_warm16_supported(segments):
 
 
 def lstm_chain_bwd_seg(w_hh, saved, d_emit, n, p0, n_calls, segments, warmup, dgates, work, seam_err, persistent=False,
-                       full_calls=0, cheap=0):
+                       full_calls=0, cheap=0, arith="f32"):
     """cheap: the first steps of the warm-up that run at 16-bit split precision in a launch of their own
-    (icrl_lstm_chain_bwd_seg_warm16; persistent launches only)."""
+    (icrl_lstm_chain_bwd_seg_warm16; persistent launches only).  arith="f16x2": the owner-computes launch on the
+    f16 matrix instruction (icrl_lstm_chain_bwd_seg_f16x2; work: chain_bwd_f16x2_workspace_floats(segments))."""
     _chain_shapes("lstm_chain_bwd_seg", n, p0, n_calls, 4, w_hh=w_hh, saved=saved, slots=6, d_emit=d_emit,
-                  dgates=(dgates,), work=work, segments=segments, full_calls=full_calls)
+                  dgates=(dgates,), work=None if arith == "f16x2" else work, segments=segments, full_calls=full_calls)
+    if arith == "f16x2":
+        assert cheap == 0 and work.numel() >= chain_bwd_f16x2_workspace_floats(segments)
+        steps = _seg_steps(n, p0, n_calls, full_calls, segments, warmup)
+        with _Timed("lstm_chain_bwd_f16x2", chain_positions(n, p0, n_calls, full_calls), steps=steps,
+                    flops=2.0 * segments * 512 * 512 * 4 * steps):
+            rc = load().icrl_lstm_chain_bwd_seg_f16x2(_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0,
+                                                      n_calls, full_calls, segments, warmup, _ptr(_f32c(dgates)),
+                                                      _ptr(_f32c(work)), _ptr(seam_err), _stream())
+        _check(rc, "icrl_lstm_chain_bwd_seg_f16x2")
+        return
     assert cheap == 0 or persistent, "the 16-bit warm-up belongs to the persistent launch"
     steps = _seg_steps(n, p0, n_calls, full_calls, segments, warmup)
     head = (_ptr(_f32c(w_hh)), _ptr(_f32c(saved)), _ptr(_f32c(d_emit)), n, p0, n_calls, full_calls, segments, warmup)
@@ -789,18 +804,27 @@ def policy_lstm_bptt(gates_act, c_all, d_h, w_hh, dgates, dc0, dc1, dh0, scratch
     _check(rc, "icrl_policy_lstm_bptt")
 
 
-def policy_lstm_bptt_persist(gates_act, c_all, d_h, w_hh, dgates, dh0, work, status):
+def chain_bwd_f16x2_workspace_floats(segments):
+    return int(load().icrl_chain_bwd_f16x2_workspace_floats(int(segments)))
+
+
+def chain_bwd_f16x2_supported(segments):
+    return bool(load().icrl_chain_bwd_f16x2_supported(int(segments)))
+
+
+def policy_lstm_bptt_persist(gates_act, c_all, d_h, w_hh, dgates, dh0, work, status, arith="f32"):
     """The policy LSTM's backward-through-time over all T steps as ONE persistent launch (the backward chain kernel
     on N per-row chains with a gradient injected at every step); d_h is read only.  Needs chain_pair_supported(N)."""
     t_steps, n = gates_act.shape[0], gates_act.shape[1]
     assert gates_act.shape == (t_steps, n, 2048) and c_all.shape[0] >= t_steps + 1 and c_all.shape[1:] == (n, 512)
     assert d_h.shape == (t_steps, n, 512) and dgates.shape == (t_steps, n, 2048) and w_hh.shape == (2048, 512)
-    assert dh0.shape == (n, 512) and work.numel() >= chain_seg_workspace_floats(n)
+    need = chain_bwd_f16x2_workspace_floats(n) if arith == "f16x2" else chain_seg_workspace_floats(n)
+    assert dh0.shape == (n, 512) and work.numel() >= need
     assert status.dtype == torch.int32 and status.numel() >= 1
+    fn = load().icrl_policy_lstm_bptt_f16x2 if arith == "f16x2" else load().icrl_policy_lstm_bptt_persist
     with _Timed("policy_bptt", t_steps, steps=t_steps + 1, flops=2.0 * t_steps * n * 512 * 2048):
-        rc = load().icrl_policy_lstm_bptt_persist(_ptr(_f32c(gates_act)), _ptr(_f32c(c_all)), _ptr(_f32c(d_h)),
-                                                  _ptr(_f32c(w_hh)), n, t_steps, _ptr(_f32c(dgates)), _ptr(_f32c(dh0)),
-                                                  _ptr(_f32c(work)), _ptr(status), _stream())
+        rc = fn(_ptr(_f32c(gates_act)), _ptr(_f32c(c_all)), _ptr(_f32c(d_h)), _ptr(_f32c(w_hh)), n, t_steps,
+                _ptr(_f32c(dgates)), _ptr(_f32c(dh0)), _ptr(_f32c(work)), _ptr(status), _stream())
     _check(rc, "icrl_policy_lstm_bptt_persist")
 
 

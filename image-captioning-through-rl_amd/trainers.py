@@ -225,7 +225,8 @@ def _a2c_minibatch(engine, optimizer, captions, features, p0, n_steps):
         # starts as soon as the engine says so and runs beside the value chain's backward pass
         averager = getattr(engine, "_averager", None)
         if averager is None or averager.flat_grad is not flat.flat_grad:
-            averager = engine._averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."))
+            averager = engine._averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."),
+                                                               stream=engine.side_stream())
         engine.on_policy_grads = averager.start_early
     res = engine.step(feats, prefix, n_steps, uniforms=uniforms)
     if averager is not None:

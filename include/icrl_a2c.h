@@ -170,6 +170,25 @@ int icrl_policy_lstm_bptt(const float* gates_act, const float* c_all, float* dH,
 int icrl_policy_lstm_bptt_persist(const float* gates_act, const float* c_all, const float* d_h, const float* w_hh,
                                   int N, int T, float* dgates, float* dh0, float* work, int* status,
                                   icrl_stream_t stream);
+/* The backward chains above as an owner-computes launch on the f16 matrix instruction: dh = dgates . W_hh sums over
+ * all 2048 gate rows, and a workgroup multiplies only the 128 gate gradients it produced itself by its rows of
+ * W_hh (partial[32 segments][512 units]), hands every workgroup of its row group the 32 x 32 tile of that one's
+ * units and adds up the 16 tiles it is sent: half the exchanged bytes of the gathering launch, and the gate
+ * gradients never leave the workgroup, so they are cut into two f16 pieces with a power-of-two scale per segment
+ * row (W_hh's slice: one scale per wave, cut once, kept in registers); products hi.hi + hi.mid + mid.hi with
+ * float32 sums, 2^-21 per element product, the exchanged partial sums float32.  Same arguments, outputs and seam
+ * errors as icrl_lstm_chain_bwd_seg_persist / icrl_policy_lstm_bptt_persist (trainers.py:479's autograd through
+ * models.py:133 / :80); work: icrl_chain_bwd_f16x2_workspace_floats(segments or N) floats.  Results agree with the
+ * float32 launches to float32 rounding, not bit for bit.  icrl_chain_bwd_f16x2_supported: whether it fits the device. */
+int64_t icrl_chain_bwd_f16x2_workspace_floats(int segments);
+int icrl_chain_bwd_f16x2_supported(int segments);
+int icrl_lstm_chain_bwd_seg_f16x2(const float* w_hh, const float* saved, const float* d_emit, int N, int p0,
+                                  int n_calls, int full_calls, int segments, int warmup, float* dgates, float* work,
+                                  float* seam_err, icrl_stream_t stream);
+int icrl_policy_lstm_bptt_f16x2(const float* gates_act, const float* c_all, const float* d_h, const float* w_hh,
+                                int N, int T, float* dgates, float* dh0, float* work, int* status,
+                                icrl_stream_t stream);
+
 
 /* One whole step of the policy LSTM in a single launch (models.py:73 + :80 for one position):
  * x = emb[tokens[i]], gates = x*W_ih^T + h_cur*W_hh^T + b_ih + b_hh, then the cell.  Writes the

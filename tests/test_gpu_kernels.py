@@ -835,6 +835,16 @@ def test_persistent_policy_lstm_bptt_against_the_launches_issued_one_by_one(n, t
         scale = dgp.abs().max().item()
         assert (dgp2 - dgp).abs().max().item() <= 2e-5 * scale
         assert (dh02 - dh0).abs().max().item() <= 2e-5 * dh0.abs().max().item()
+    # the owner-computes launch on the f16 matrix instruction
+    assert hip.chain_bwd_f16x2_supported(n)
+    work_b = torch.zeros(hip.chain_bwd_f16x2_workspace_floats(n), device="cuda")
+    for _ in range(2):
+        dgp3, dh03 = torch.full_like(dgp, float("nan")), torch.full_like(dh0, float("nan"))
+        hip.policy_lstm_bptt_persist(gates, c_all, d_out, w_hh, dgp3, dh03, work_b, status, arith="f16x2")
+        torch.cuda.synchronize()
+        assert int(status[0]) == 0
+        assert (dgp3 - dgp).abs().max().item() <= 2e-5 * scale
+        assert (dh03 - dh0).abs().max().item() <= 2e-5 * dh0.abs().max().item()
 
 
 @pytest.mark.parametrize("n,p0,calls,segs,warm", [(64, 1, 19, 32, 64), (48, 2, 12, 96, 16), (512, 1, 19, 256, 96)])
@@ -889,3 +899,48 @@ def test_forward_chain_pair_on_the_f16_matrix_instruction(n, p0, calls, segs, wa
         worst_new = max(worst_new, (new[1][pos, 5].cpu().double() - h).abs().max().item())
         worst_ref = max(worst_ref, (ref[1][pos, 5].cpu().double() - h).abs().max().item())
     assert worst_new <= 4e-6 and worst_new <= 4.0 * worst_ref + 1e-6, (worst_new, worst_ref)
+
+
+@pytest.mark.parametrize("n,p0,calls,segs,warm,fc", [(64, 1, 19, 32, 64, 0), (48, 2, 12, 96, 16, 0), (512, 1, 19, 256, 96, 1),
+                                                     (40, 1, 12, 50, 24, 2)])
+def test_backward_chain_owner_computes_launch_on_the_f16_instruction(n, p0, calls, segs, warm, fc):
+    """icrl_lstm_chain_bwd_seg_f16x2 (each workgroup multiplies its own gate gradients, partial sums exchanged, f16
+    pieces with a scale per segment row) against the float32 gathering launch on the same kept activations: every gate
+    gradient to 2e-6 of the largest one, the same seam verdict, twice in a row; with injected gradients spanning six
+    orders of magnitude over the calls, so that the per-row scaling is exercised."""
+    assert hip.chain_pair_supported(segs) and hip.chain_bwd_f16x2_supported(segs)
+    rs = np.random.RandomState(segs + 9)
+    cols = p0 + calls - 1
+    positions = hip.chain_positions(n, p0, calls, fc)
+    xv, wv = _chain_inputs(rs, n, cols, 4)
+    xv_d, wv_d = dev(xv), dev(wv)
+    work_v, err_v = _seg_ws(segs)
+    h_s, saved_s = torch.zeros(calls, n, H, device="cuda"), torch.zeros(positions, 6, H, device="cuda")
+    hip.lstm_chain_fwd_seg(xv_d, wv_d, n, p0, calls, segs, warm, h_s, saved_s, work_v, err_v, persistent=True, full_calls=fc)
+    d_emit = rnd(rs, calls, n, H, scale=0.01)
+    d_emit *= (10.0 ** rs.uniform(-5, 1, size=(calls, 1, 1))).astype(np.float32)
+    d_emit = dev(d_emit)
+    dg_ref = torch.zeros(positions, 4 * H, device="cuda")
+    err_ref, err_new = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    hip.lstm_chain_bwd_seg(wv_d, saved_s, d_emit, n, p0, calls, segs, warm, dg_ref, work_v, err_ref, persistent=True,
+                           full_calls=fc)
+    work_b = torch.zeros(hip.chain_bwd_f16x2_workspace_floats(segs), device="cuda")
+    first = None
+    for _ in range(2):
+        dg_new = torch.full_like(dg_ref, float("nan"))
+        hip.lstm_chain_bwd_seg(wv_d, saved_s, d_emit, n, p0, calls, segs, warm, dg_new, work_b, err_new, full_calls=fc,
+                               arith="f16x2")
+        torch.cuda.synchronize()
+        assert torch.isfinite(dg_new).all()
+        top = dg_ref.abs().max().item()
+        assert (dg_new - dg_ref).abs().max().item() <= 2e-6 * top, ((dg_new - dg_ref).abs().max().item(), top)
+        # row by row as well: a position whose gradients are tiny beside the largest is held to its own scale
+        rows_top = dg_ref.abs().amax(dim=1)
+        rel = ((dg_new - dg_ref).abs().amax(dim=1) / rows_top.clamp_min(1e-30))[rows_top > 1e-12 * top]
+        assert rel.max().item() <= 2e-4, rel.max().item()
+        e_ref, e_new = err_ref.tolist(), err_new.tolist()
+        assert abs(e_new[1] - e_ref[1]) <= 1e-5 * e_ref[1] + 1e-30
+        assert abs(e_new[0] - e_ref[0]) <= 2e-6 * e_ref[1] + 1e-30
+        if first is not None:
+            assert torch.equal(dg_new, first) and e_new == first_err
+        first, first_err = dg_new, e_new

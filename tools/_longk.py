@@ -14,5 +14,5 @@ for r in rows[a+1:b+1]:
     s,e=int(r["Start_Timestamp"]),int(r["End_Timestamp"])
     d=(e-s)/1e3
     nm=short(r["Kernel_Name"])
-    if (s-t0)/1e3>2000 and (d>=thr or nm.startswith(("seg","adam","seam"))):
+    if (s-t0)/1e3>float(sys.argv[4] if len(sys.argv)>4 else 2000) and (d>=thr or nm.startswith(("seg","adam","seam"))):
         print("%8.1f %8.1f  q%s %-32s" % ((s-t0)/1e3,d,r["Queue_Id"],nm[:32]))
