@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--pretrain", type=int, default=0,
                     help="run each of the three pre-training loops for this many minibatches first and bench the A2C "
                          "step on the networks they produce (trained-regime run, reported under its own workload name)")
+    ap.add_argument("--rollout-arith", default=None, choices=("f32", "f16x2"),
+                    help="the rollout's per-round vocabulary/gate product (default: the engine's, f16x2)")
     ap.add_argument("--chain-arith", default=None, choices=("f32", "f16x2"),
                     help="recurrent products of the forward chains' persistent launch (default: the engine's)")
     ap.add_argument("--max-streams", type=int, default=None, choices=(3, 4),
@@ -242,6 +244,8 @@ def main():
         engine_opts["warm16"] = False
     if args.chain_arith is not None:
         engine_opts["chain_arith"] = args.chain_arith
+    if args.rollout_arith is not None:
+        engine_opts["rollout_arith"] = args.rollout_arith
     if args.no_late_policy_bptt:
         engine_opts["late_policy_bptt"] = False
     if args.policy_dtype != "f32":

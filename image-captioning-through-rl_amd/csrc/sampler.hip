@@ -53,6 +53,7 @@ struct NextCell {
     const float* c_prev;
     float* c_out;
     float* h_out;
+    _Float16* h_pieces;   // optional: the new h once more, as the two scaled f16 pieces icrl_gemm_f16x2 takes (scale 2^12)
 };
 
 // DL: the `probs` output receives onehot(token) - softmax instead of the softmax (what the policy's backward pass
@@ -246,6 +247,17 @@ __global__ __launch_bounds__(NT) void sample_kernel(const float* __restrict__ lo
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float2*>(go_ + q * H + u) = g4[q];
             *reinterpret_cast<float2*>(cell.c_out + (int64_t)r * H + u) = c;
             *reinterpret_cast<float2*>(cell.h_out + (int64_t)r * H + u) = h;
+            if (cell.h_pieces) {
+                // fragment order of icrl_cut_f16x2: row block r / 32, k block u / 16, lane r % 32 + 32 (u % 16 / 8)
+                typedef _Float16 hf16x2 __attribute__((ext_vector_type(2)));
+                hf16x2 hi, mid;
+                const float sx = h.x * 4096.f, sy = h.y * 4096.f;
+                hi[0] = (_Float16)sx; hi[1] = (_Float16)sy;
+                mid[0] = (_Float16)(sx - (float)hi[0]); mid[1] = (_Float16)(sy - (float)hi[1]);
+                _Float16* dst = cell.h_pieces + ((((int64_t)(r >> 5) * (H / 16) + (u >> 4)) * 2) * 64 + (r & 31) + 32 * ((u >> 3) & 1)) * 8 + (u & 7);
+                *reinterpret_cast<hf16x2*>(dst) = hi;
+                *reinterpret_cast<hf16x2*>(dst + 64 * 8) = mid;
+            }
         }
     }
 }
@@ -349,7 +361,8 @@ extern "C" int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logi
                                             const double* uniforms, int64_t* tokens_out, int64_t token_stride,
                                             float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
                                             const float* pre, int64_t ld_pre, const float* table, float* gates_out,
-                                            const float* c_prev, float* c_out, float* h_out, icrl_stream_t stream) {
+                                            const float* c_prev, float* c_out, float* h_out, void* h_pieces,
+                                            icrl_stream_t stream) {
     ICRL_REQUIRE(logits && tokens_out && N > 0 && V > 0, "icrl_sample_tokens_lstm_cell: null pointer or empty shape");
     ICRL_REQUIRE(ld_logits >= V, "icrl_sample_tokens_lstm_cell: ld_logits < V");
     ICRL_REQUIRE((int64_t)V * 4 <= 64 * 1024, "icrl_sample_tokens_lstm_cell: vocabulary %d exceeds the 16384-entry LDS row", V);
@@ -360,7 +373,8 @@ extern "C" int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logi
     ICRL_REQUIRE(pre && table && gates_out && c_prev && c_out && h_out, "icrl_sample_tokens_lstm_cell: null cell operand");
     ICRL_REQUIRE(ld_pre >= 2048 && ld_pre % 2 == 0 && reinterpret_cast<uintptr_t>(pre) % 8 == 0,
                  "icrl_sample_tokens_lstm_cell: pre must be 8-byte aligned with an even row stride >= 2048");
-    NextCell cell{pre, ld_pre, table, gates_out, c_prev, c_out, h_out};
+    ICRL_REQUIRE(reinterpret_cast<uintptr_t>(h_pieces) % 16 == 0, "icrl_sample_tokens_lstm_cell: h_pieces must be 16-byte aligned");
+    NextCell cell{pre, ld_pre, table, gates_out, c_prev, c_out, h_out, static_cast<_Float16*>(h_pieces)};
     return launch_sampler(logits, ld_logits, N, V, mode, uniforms, tokens_out, token_stride, log_prob, log_prob_stride,
                           probs, entropy, cell, stream);
 }

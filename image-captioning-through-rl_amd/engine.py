@@ -187,7 +187,7 @@ class A2CEngine:
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
                  frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f32x3", late_policy_bptt=True,
-                 chain_arith="f16x2",
+                 chain_arith="f16x2", rollout_arith="f16x2",
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -234,6 +234,13 @@ class A2CEngine:
         # W_hh in registers, 16-unit tiles), "f32" = the exact float32 instruction (with the 16-bit warm-up part, if on)
         assert chain_arith in ("f32", "f16x2")
         self.chain_arith = chain_arith
+        # the rollout's per-round product h . [linear2vocab.weight ; lstm.weight_hh]^T (sampled and teacher-forced
+        # rollouts, float32 policy arithmetic): "f16x2" = weights cut once per minibatch into two scaled f16 pieces,
+        # h cut by the sampler launch that produces it, three piece products per element product (float32
+        # rounding-level accuracy; a third of the exact kernel's time), "f32" = the exact float32 instruction.
+        # Greedy decoding always takes the exact kernel.
+        assert rollout_arith in ("f32", "f16x2")
+        self.rollout_arith = rollout_arith
         # the policy LSTM's backward-through-time as one persistent launch behind the value chain's (see _tail_ok)
         self.late_policy_bptt = bool(late_policy_bptt)
         self._warm16b_off, self._warm16b_penalty = 0, 32
@@ -594,6 +601,9 @@ class A2CEngine:
     def _padded_vocab(self):
         return (self.vocab + 63) // 64 * 64
 
+    def _rollout_f16x2(self):
+        return self.rollout_arith == "f16x2" and self.pd == "f32"
+
     def _policy_table(self, ws):
         """Per-word input side of the policy LSTM, table[w] = W_ih emb[w] + b_ih + b_hh (models.py:73, 80), and
         the vocabulary projection stacked on W_hh, so that one product gives a step's logits and the recurrent
@@ -612,6 +622,13 @@ class A2CEngine:
         ws["Wcat"][:V].copy_(P["linear2vocab.weight"])
         ws["Wcat"][Vp:].copy_(P["lstm.weight_hh_l0"])
         ws["bcat"][:V].copy_(P["linear2vocab.bias"])
+        if self._rollout_f16x2():
+            if "Wcat_p" not in ws:
+                rows = ws["logits"].shape[0]
+                ws["Wcat_p"], ws["Wcat_d"] = hip.f16x2_pieces(Vp + 4 * H, H, self.device)
+                ws["h_p"], ws["h_d"] = hip.f16x2_pieces(rows, H, self.device)
+                ws["h_d"].fill_(1.0 / 4096.0)
+            hip.cut_f16x2(ws["Wcat"], ws["Wcat_p"], ws["Wcat_d"])
         hip.gemm(P["caption_embedding.weight"], P["lstm.weight_ih_l0"], ws["table_p"], bias=P["lstm.bias_ih_l0"],
                  bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
 
@@ -635,6 +652,7 @@ class A2CEngine:
         fused_step = self.E % 64 == 0 and self.pd == "f32"
         mode_s = mode if mode == hip.GREEDY else mode | hip.EMIT_DLOGITS
         cell_done = False
+        h_cut = False   # the newest h is already in ws["h_p"] (left there by the sampler launch that computed it)
         for k in range(t_steps):
             if not cell_done:
                 self._rollout_cell(ws, k, n, fused_step)
@@ -652,7 +670,14 @@ class A2CEngine:
                     torch.cuda.current_stream().wait_event(ev_table)
                     ev_table = True
                 ext = ws["logits_ext"][:n]
-                hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3, dtype=self.pd)
+                if self._rollout_f16x2():
+                    if not h_cut:
+                        hip.cut_f16x2(Hb[k + 1], ws["h_p"], ws["h_d"], fixed_scale=4096.0)
+                    hip.gemm_f16x2(ws["h_p"], ws["h_d"], ws["Wcat_p"], ws["Wcat_d"], ext, H, bias=ws["bcat"])
+                    out["h_pieces"] = ws["h_p"]
+                    h_cut = True
+                else:
+                    hip.gemm(Hb[k + 1], ws["Wcat"], ext, bias=ws["bcat"], tile=3, dtype=self.pd)
                 hip.sample_tokens_lstm_cell(ext[:, :V], mode_s, tokT[k + 1], 1, ext[:, self._padded_vocab():], ws["table_p"], gates[k + 1],
                                             Cb[k + 1], Cb[k + 2], Hb[k + 2], **out)
                 cell_done = True

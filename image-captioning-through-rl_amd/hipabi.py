@@ -31,6 +31,9 @@ SIGNATURES = {
                                 c_vp, c_vp, c_int, c_int, c_vp]),
     "icrl_gemm_f32x3_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int,
                                        c_int, c_int, c_vp]),
+    "icrl_f16x2_piece_halves": (c_i64, [c_int, c_int]),
+    "icrl_cut_f16x2": (c_int, [c_vp, c_i64, c_int, c_int, ctypes.c_float, c_vp, c_vp, c_vp]),
+    "icrl_gemm_f16x2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 6),
@@ -77,7 +80,7 @@ SIGNATURES = {
     "icrl_sample_tokens": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                                    c_vp]),
     "icrl_sample_tokens_lstm_cell": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
-                                             c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                             c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "icrl_policy_dlogits": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "icrl_chain_sync_bytes": (c_i64, []),
     "icrl_lstm_chain_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -95,7 +98,7 @@ SIGNATURES = {
 
 SAMPLE, GREEDY, FORCED = 0, 1, 2
 EMIT_DLOGITS = 16   # or-ed into SAMPLE / FORCED: the probs output receives onehot(token) - softmax
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -269,6 +272,41 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     return out
 
 
+def f16x2_pieces(rows, k, device):
+    """Zeroed piece buffer and descale vector for a [rows, k] operand of gemm_f16x2 (the padding rows up to the
+    next multiple of 32 must stay zero; cut_f16x2 never writes them)."""
+    halves = load().icrl_f16x2_piece_halves(rows, k)
+    assert halves > 0, "gemm_f16x2 operands need k % 16 == 0"
+    return (torch.zeros(halves, dtype=torch.float16, device=device), torch.zeros(rows, dtype=torch.float32, device=device))
+
+
+def cut_f16x2(x, pieces, descale, fixed_scale=0.0):
+    """Cuts the rows of x [rows, k] (float32, last dimension contiguous) into two scaled f16 pieces in the matrix
+    instruction's fragment order; descale[r] = 1 / the row's power-of-two scale (its own with fixed_scale 0)."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, k = x.shape
+    assert pieces.dtype == torch.float16 and pieces.is_contiguous() and pieces.numel() >= load().icrl_f16x2_piece_halves(rows, k) > 0
+    assert descale.dtype == torch.float32 and descale.is_contiguous() and descale.numel() >= rows
+    _check(load().icrl_cut_f16x2(_ptr(x), x.stride(0), rows, k, float(fixed_scale), _ptr(pieces), _ptr(descale), _stream()),
+           "icrl_cut_f16x2")
+
+
+def gemm_f16x2(a_pieces, a_descale, b_pieces, b_descale, out, k, bias=None):
+    """out[M, N] = A . B^T (+ bias) from operands cut by cut_f16x2 (three f16 piece products per element product,
+    float32 sums: float32 rounding-level accuracy)."""
+    m, n = out.shape
+    assert out.dtype == torch.float32 and out.stride(1) == 1
+    for t, rows in ((a_pieces, m), (b_pieces, n)):
+        assert t.dtype == torch.float16 and t.is_contiguous() and t.numel() >= load().icrl_f16x2_piece_halves(rows, k) > 0
+    assert a_descale.numel() >= m and b_descale.numel() >= n and a_descale.dtype == b_descale.dtype == torch.float32
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() >= n)
+    with _Timed("gemm_f16x2", 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
+        rc = load().icrl_gemm_f16x2(_ptr(a_pieces), _ptr(a_descale), _ptr(b_pieces), _ptr(b_descale), _ptr(out),
+                                    out.stride(0), m, n, k, _ptr(bias), _stream())
+    _check(rc, "icrl_gemm_f16x2")
+    return out
+
+
 def gather_rows(table, idx, idx_stride, rows, out):
     _check(load().icrl_gather_rows(_ptr(_f32c(table)), table.shape[1], _ptr(idx), idx_stride, rows, _ptr(out),
                                    _stream()), "icrl_gather_rows")
@@ -358,9 +396,10 @@ def sample_tokens(logits, mode, tokens_out, token_stride, *, uniforms=None, log_
 
 
 def sample_tokens_lstm_cell(logits, mode, tokens_out, token_stride, pre, table, gates_out, c_prev, c_out, h_out, *,
-                            uniforms=None, log_prob=None, log_prob_stride=1, probs=None, entropy=None):
+                            uniforms=None, log_prob=None, log_prob_stride=1, probs=None, entropy=None, h_pieces=None):
     """sample_tokens, then the policy LSTM's next cell update in the same launch: gates = pre[i] + table[token_i].
-    logits [N,V] and pre [N,2048] may be column ranges of one wider matrix (row strides are passed)."""
+    logits [N,V] and pre [N,2048] may be column ranges of one wider matrix (row strides are passed).  h_pieces:
+    a gemm_f16x2 piece buffer for [N, 512] that receives the new h cut at scale 4096."""
     n, v = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1 and tokens_out.dtype == torch.int64
     assert pre.dtype == torch.float32 and pre.shape == (n, 2048) and pre.stride(1) == 1
@@ -369,10 +408,14 @@ def sample_tokens_lstm_cell(logits, mode, tokens_out, token_stride, pre, table, 
         assert t.dtype == torch.float32 and t.shape == (n, width) and t.is_contiguous()
     if uniforms is not None:
         assert uniforms.dtype == torch.float64 and uniforms.is_contiguous() and uniforms.numel() >= n
+    if h_pieces is not None:
+        assert h_pieces.dtype == torch.float16 and h_pieces.is_contiguous()
+        assert h_pieces.numel() >= load().icrl_f16x2_piece_halves(n, 512)
     _check(load().icrl_sample_tokens_lstm_cell(_ptr(logits), logits.stride(0), n, v, mode, _ptr(uniforms), _ptr(tokens_out),
                                                token_stride, _ptr(log_prob), log_prob_stride, _ptr(probs), _ptr(entropy),
                                                _ptr(pre), pre.stride(0), _ptr(table), _ptr(gates_out), _ptr(c_prev),
-                                               _ptr(c_out), _ptr(h_out), _stream()), "icrl_sample_tokens_lstm_cell")
+                                               _ptr(c_out), _ptr(h_out), _ptr(h_pieces), _stream()),
+           "icrl_sample_tokens_lstm_cell")
 
 
 def masked_nll(log_probs, valid_steps, row_weight, loss, d_logp=None):

@@ -31,7 +31,7 @@ typedef void* icrl_stream_t;
 #define ICRL_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define ICRL_ERR_TIMEOUT (-3) /* a chain kernel gave up waiting for a peer workgroup */
 
-#define ICRL_ABI_VERSION 2
+#define ICRL_ABI_VERSION 3
 
 int icrl_abi_version(void);
 const char* icrl_last_error(void);
@@ -91,6 +91,24 @@ int icrl_gemm_f32x3(const float* A, int64_t lda, int a_kmajor, const int64_t* a_
 int icrl_gemm_f32x3_splitk(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
                            int b_kmajor, float* C_slabs, int64_t ldc, int64_t slab_stride, int M,
                            int N, int K, int splits, int tile, icrl_stream_t stream);
+
+/* C = A . B^T (+ bias) for operands cut once and multiplied many times: the rollout's per-round product of the
+ * newest h with [linear2vocab.weight ; lstm.weight_hh] (models.py:80-82 run one column at a time, trainers.py:443-458),
+ * whose weights are constant over the minibatch's 19 rounds.  icrl_cut_f16x2 scales each row of x [rows, K] (row
+ * stride ld floats) by a power of two - its own, so that the row's largest entry lands in [2^10, 2^11), or
+ * fixed_scale > 0 for rows known to lie within [-1, 1] (fixed_scale 4096) - and cuts it into two f16 pieces
+ * (x s = hi + mid to 2^-22 relative), stored in the matrix instruction's fragment order: rows in blocks of 32, k in
+ * blocks of 16, block (rb, kb) piece p lane l = r % 32 + 32 (k % 16 / 8) at (((rb K/16 + kb) 2 + p) 64 + l) 8 + k % 8
+ * halves; descale[r] = 1 / s.  `pieces` holds icrl_f16x2_piece_halves(rows, K) halves (rows rounded up to 32: the rows
+ * of the padding are never written and must be zero, so zero the buffer once).  icrl_gemm_f16x2 computes
+ * C[m, n] = (sum_k hi.hi + hi.mid + mid.hi) a_descale[m] b_descale[n] + bias[n] on v_mfma_f32_32x32x16_f16 with
+ * float32 sums: each element product to about 2^-21, i.e. float32 rounding level for these 512-term sums; not bit
+ * for bit the f32 kernel's result.  K % 16 == 0.  128 x 192 tiles, fragments loaded straight from memory (no LDS). */
+int64_t icrl_f16x2_piece_halves(int rows, int K);
+int icrl_cut_f16x2(const float* x, int64_t ld, int rows, int K, float fixed_scale, void* pieces, float* descale,
+                   icrl_stream_t stream);
+int icrl_gemm_f16x2(const void* a_pieces, const float* a_descale, const void* b_pieces, const float* b_descale,
+                    float* C, int64_t ldc, int M, int N, int K, const float* bias, icrl_stream_t stream);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
 int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
@@ -226,12 +244,15 @@ int icrl_sample_tokens(const float* logits, int64_t ld_logits, int N, int V, int
  * token w forms gates = pre[i] + table[w], applies the cell to c_prev[i] and writes the activated gates
  * (i, f, g, o; [N,2048]), c_out and h_out ([N,512]).  pre [N, >= 2048] (row stride ld_pre) = h . W_hh^T of the
  * state the logits were computed from, without bias; table [V,2048] = W_ih emb[w] + b_ih + b_hh for every
- * word w.  One launch less, and no matrix product, between a token and the next step's logits. */
+ * word w.  One launch less, and no matrix product, between a token and the next step's logits.  h_pieces
+ * (optional) receives the new h once more as the operand of icrl_gemm_f16x2: icrl_cut_f16x2's layout for [N, 512]
+ * with fixed_scale 4096 (the descale vector is then 2^-12 in every entry). */
 int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logits, int N, int V, int mode,
                                  const double* uniforms, int64_t* tokens_out, int64_t token_stride,
                                  float* log_prob, int64_t log_prob_stride, float* probs, float* entropy,
                                  const float* pre, int64_t ld_pre, const float* table, float* gates_out,
-                                 const float* c_prev, float* c_out, float* h_out, icrl_stream_t stream);
+                                 const float* c_prev, float* c_out, float* h_out, void* h_pieces,
+                                 icrl_stream_t stream);
 
 /* values[r, 0..k) / indices[r, 0..k) = the k largest entries of logits[r, 0..V) in descending order,
  * ties by lowest index: torch.topk(output[:, -1:, :], beamSize) of the look-ahead decoder,

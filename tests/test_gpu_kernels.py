@@ -650,10 +650,17 @@ def test_sampler_with_next_cell_update(mode):
     logits = ext[:, :v].contiguous()
     hip.sample_tokens(logits, m, tok_a, 1, uniforms=u if mode == "sample" else None, log_prob=lp_a, probs=pr_a)
     gates, c_out, h_out = (torch.zeros(n, w, device="cuda") for w in (4 * hh, hh, hh))
+    h_pieces, _ = hip.f16x2_pieces(n, hh, "cuda")
     hip.sample_tokens_lstm_cell(ext[:, :v], m, tok_b, 1, ext[:, v:], table, gates, c_prev, c_out, h_out,
-                                uniforms=u if mode == "sample" else None, log_prob=lp_b, probs=pr_b)
+                                uniforms=u if mode == "sample" else None, log_prob=lp_b, probs=pr_b, h_pieces=h_pieces)
     torch.cuda.synchronize()
     assert torch.equal(tok_a, tok_b) and torch.equal(lp_a, lp_b) and torch.equal(pr_a, pr_b)
+    # the pieces the launch leaves for the next round's product are those the cutter makes of its h, bit for bit
+    want_pieces, want_descale = hip.f16x2_pieces(n, hh, "cuda")
+    hip.cut_f16x2(h_out, want_pieces, want_descale, fixed_scale=4096.0)
+    torch.cuda.synchronize()
+    assert torch.equal(h_pieces.view(torch.int16), want_pieces.view(torch.int16))
+    assert torch.equal(want_descale, torch.full((n,), 2.0 ** -12, device="cuda"))
     pre = ext[:, v:].double().cpu() + table.double().cpu()[tok_b.cpu()]
     i, f, g, o = (pre[:, q * hh:(q + 1) * hh] for q in range(4))
     i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
@@ -662,6 +669,87 @@ def test_sampler_with_next_cell_update(mode):
     np.testing.assert_allclose(gates.cpu().numpy(), torch.cat((i, f, g, o), 1).numpy(), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(c_out.cpu().numpy(), c.numpy(), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(h_out.cpu().numpy(), h.numpy(), rtol=2e-6, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- pre-cut f16 pieces
+def _pieces_to_matrix(pieces, descale, rows, k):
+    """The value a piece buffer stands for, (hi + mid) * descale, as a float64 [rows, k] matrix."""
+    rb, kb = -(-rows // 32), k // 16
+    p = pieces.cpu().double().view(rb, kb, 2, 2, 32, 8)          # row block, k block, piece, k half, row, k
+    x = (p[:, :, 0] + p[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(rb * 32, k)   # -> [row block, row, k block, half, k]
+    return x[:rows] * descale.cpu().double()[:, None], x[rows:]
+
+
+@pytest.mark.parametrize("rows,k,fixed", [(70, 48, 0.0), (512, 512, 4096.0), (1000, 512, 0.0), (33, 2048, 0.0)])
+def test_f16x2_cutter_pieces_add_up_to_the_element(rows, k, fixed):
+    """hi + mid, descaled, is the float32 element to 2^-22 of the row's largest entry (exactly that relative to the
+    element itself wherever both pieces are normal f16 numbers); the padding rows stay zero; a fixed scale is used as
+    given; rows may be slices of a wider matrix."""
+    rs = np.random.RandomState(rows + k)
+    wide = dev(rnd(rs, rows, k + 16) * np.exp(rs.standard_normal((rows, 1)) * 3).astype(np.float32))
+    if fixed:
+        wide = torch.tanh(wide)
+    x = wide[:, 4:4 + k] if not fixed else wide[:, :k]
+    if not fixed:
+        x[min(5, rows - 1)] = 0.
+    pieces, descale = hip.f16x2_pieces(rows, k, "cuda")
+    hip.cut_f16x2(x, pieces, descale, fixed_scale=fixed)
+    torch.cuda.synchronize()
+    got, padding = _pieces_to_matrix(pieces, descale, rows, k)
+    assert not padding.any()
+    xd = x.cpu().double()
+    top = xd.abs().max(dim=1, keepdim=True).values
+    if fixed:
+        assert torch.equal(descale.cpu(), torch.full((rows,), 1.0 / fixed))
+        top = torch.ones_like(top)
+    else:
+        scaled_top = top[:, 0] / descale.cpu().double()
+        nz = top[:, 0] > 0
+        assert ((scaled_top[nz] >= 1024) & (scaled_top[nz] < 2048)).all()
+    assert ((got - xd).abs() <= 2.0 ** -22 * top).all()
+    assert torch.equal(got[xd == 0], xd[xd == 0])
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 12096, 512), (64, 12096, 512), (4, 2148, 512), (70, 1001, 48), (130, 200, 1040)])
+def test_f16x2_gemm_against_float64(m, n, k):
+    """icrl_gemm_f16x2 on operands cut by icrl_cut_f16x2 against the float64 product of the float32 operands: the
+    error bound of an f32 product (a few 2^-24 of sum |a||b| per element) with room for the pieces' 2^-21; ragged
+    tiles, a k that is not a multiple of the pipeline depth, a vocabulary-shaped and an unaligned n (single-float
+    stores) included.  Rows of A span several orders of magnitude (each has its own scale)."""
+    rs = np.random.RandomState(m + n + k)
+    a = dev(rnd(rs, m, k) * np.exp(rs.standard_normal((m, 1)) * 2).astype(np.float32))
+    b = dev(rnd(rs, n, k, scale=0.05) * np.exp(rs.standard_normal((n, 1))).astype(np.float32))
+    bias = dev(rnd(rs, n))
+    ap, ad = hip.f16x2_pieces(m, k, "cuda")
+    bp, bd = hip.f16x2_pieces(n, k, "cuda")
+    hip.cut_f16x2(a, ap, ad)
+    hip.cut_f16x2(b, bp, bd)
+    wide = torch.full((m, n + 3), 7.0, device="cuda")
+    out = wide[:, :n] if n % 4 else torch.empty(m, n, device="cuda")
+    hip.gemm_f16x2(ap, ad, bp, bd, out, k, bias=bias)
+    plain = torch.empty(m, n, device="cuda")
+    hip.gemm_f16x2(ap, ad, bp, bd, plain, k)
+    torch.cuda.synchronize()
+    want = a.double() @ b.double().t()
+    bound = a.double().abs() @ b.double().abs().t()
+    err = (plain.double() - want).abs() / bound
+    print("%d x %d x %d: max |error| / sum|a||b| = %.3g" % (m, n, k, err.max().item()))
+    assert err.max().item() < 1e-6
+    np.testing.assert_array_equal(out.cpu().numpy(), (plain + bias).cpu().numpy())
+    if n % 4:
+        assert (wide[:, n:] == 7.0).all()
+
+
+def test_f16x2_gemm_rejects_what_it_does_not_do():
+    pieces, descale = hip.f16x2_pieces(32, 32, "cuda")
+    out = torch.empty(32, 32, device="cuda")
+    with pytest.raises(AssertionError):
+        hip.f16x2_pieces(32, 24, "cuda")                       # k not a multiple of 16
+    with pytest.raises(AssertionError):
+        hip.gemm_f16x2(pieces, descale, pieces, descale, torch.empty(64, 32, device="cuda"), 32)   # A buffer too small
+    rc = hip.load().icrl_gemm_f16x2(pieces.data_ptr(), descale.data_ptr(), pieces.data_ptr(), descale.data_ptr(),
+                                    out.data_ptr(), 16, 32, 32, 32, None, None)
+    assert rc != 0 and b"ldc" in hip.load().icrl_last_error()
 
 
 # --------------------------------------------------------------------------- policy LSTM backward-through-time
