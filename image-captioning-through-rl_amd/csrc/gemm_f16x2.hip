@@ -19,8 +19,8 @@
 //
 // Tiling.  256 threads as 2 x 2 waves, wave tile 64 x 96 (2 x 3 blocks, 96 accumulator registers), workgroup tile
 // 128 x 192: the rollout's [512 x 512] . [512 x 12096] is 4 x 63 workgroups, one per CU.  Four k blocks of fragment
-// loads are in flight per wave.  Workgroup b runs on XCD b % 8; the workgroups of one tile column (same B rows) share
-// an XCD, so that a B tile crosses the fabric once.
+// loads are in flight per wave.  Workgroup b runs on XCD b % 8; the workgroups that share an operand tile run on one
+// XCD, so that the tile crosses the fabric once.
 #include "icrl_common.h"
 
 namespace {
@@ -96,9 +96,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_kernel(HpGemmArgs g) {
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
-    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
-    const int nt = (slot / tiles_m) * 8 + xcd, mt = slot % tiles_m;
-    if (nt >= tiles_n) return;
+    // Workgroup b runs on XCD b % 8.  Every XCD takes one contiguous run of tile ids, and ids advance fastest along
+    // the dimension with fewer tiles: the few workgroups that share the other operand's tile (for the rollout, the
+    // four row tiles that share 192 rows of the weights) run side by side on one XCD and fetch it once.
+    const int per = (tiles_m * tiles_n + 7) / 8;
+    const int id = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if ((int)(blockIdx.x / 8) >= per || id >= tiles_m * tiles_n) return;
+    const bool m_fast = tiles_m <= tiles_n;
+    const int mt = m_fast ? id % tiles_m : id / tiles_n, nt = m_fast ? id / tiles_m : id % tiles_n;
     const int KB = g.K / 16;
     const int MB = (g.M + 31) / 32, NB = (g.N + 31) / 32;
     const int mb0 = (mt * TM) / 32 + wr * MI, nb0 = (nt * TN) / 32 + wc * NJ;
@@ -251,7 +256,7 @@ extern "C" int icrl_gemm_f16x2(const void* a_pieces, const float* a_descale, con
     g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     constexpr int MI = 2, NJ = 3;
     const int tiles_m = (M + 64 * MI - 1) / (64 * MI), tiles_n = (N + 64 * NJ - 1) / (64 * NJ);
-    const dim3 grid(8 * tiles_m * ((tiles_n + 7) / 8));
+    const dim3 grid(8 * ((tiles_m * tiles_n + 7) / 8));
     hipLaunchKernelGGL((gemm_f16x2_kernel<MI, NJ>), grid, dim3(256), 0, icrl::as_stream(stream), g);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;

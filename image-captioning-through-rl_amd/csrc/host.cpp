@@ -59,3 +59,27 @@ extern "C" int icrl_policy_lstm_bptt(const float* gates_act, const float* c_all,
     }
     return ICRL_OK;
 }
+
+extern "C" int icrl_policy_rollout_rounds(const void* w_pieces, const float* w_descale, const float* bias, void* h_pieces,
+                                          const float* h_descale, float* ext, int64_t ld_ext, int N, int V, int pre_col,
+                                          int rounds, int mode, const double* uniforms, int64_t* tokens, float* log_prob,
+                                          float* probs, float* entropy, const float* table, float* gates,
+                                          const float* c_state, float* h_state, icrl_stream_t stream) {
+    constexpr int H = icrl::kHidden;
+    ICRL_REQUIRE(rounds >= 0 && N > 0 && V > 0 && pre_col >= V && ld_ext >= pre_col + 4 * H,
+                 "icrl_policy_rollout_rounds: bad shape (rounds %d, N %d, V %d, pre_col %d, ld_ext %lld)", rounds, N, V, pre_col,
+                 (long long)ld_ext);
+    const int64_t nh = (int64_t)N * H;
+    for (int r = 0; r < rounds; ++r) {
+        if (int rc = icrl_gemm_f16x2(h_pieces, h_descale, w_pieces, w_descale, ext, ld_ext, N, pre_col + 4 * H, H, bias, stream))
+            return rc;
+        if (int rc = icrl_sample_tokens_lstm_cell(ext, ld_ext, N, V, mode, uniforms ? uniforms + (int64_t)r * N : nullptr,
+                                                  tokens + (int64_t)r * N, 1, log_prob + (int64_t)r * N, 1,
+                                                  probs ? probs + (int64_t)r * N * V : nullptr,
+                                                  entropy ? entropy + (int64_t)r * N : nullptr, ext + pre_col, ld_ext, table,
+                                                  gates + 4 * r * nh, c_state + r * nh, const_cast<float*>(c_state) + (r + 1) * nh,
+                                                  h_state + r * nh, h_pieces, stream))
+            return rc;
+    }
+    return ICRL_OK;
+}

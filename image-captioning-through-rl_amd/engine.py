@@ -589,7 +589,7 @@ class A2CEngine:
         return None if strict else first
 
     TABLE_ROWS_FACTOR = 16   # the table is built beside the rollout: worth it down to a sixteenth of the vocabulary in (step, row) pairs (batch 64 at vocabulary 10 000: 5.84 -> 5.56 ms)
-    NEXT_CELL_FROM = 2   # first rollout step whose cell update is done by the previous step's sampler launch
+    NEXT_CELL_FROM = 1   # first rollout step whose cell update is done by the previous step's sampler launch
 
     def _policy_table_wanted(self, n, p0, s, mode):
         """Whether the rollout takes the policy LSTM's input side from a per-word table and its cell update from
@@ -602,7 +602,7 @@ class A2CEngine:
         return (self.vocab + 63) // 64 * 64
 
     def _rollout_f16x2(self):
-        return self.rollout_arith == "f16x2" and self.pd == "f32"
+        return self.rollout_arith == "f16x2" and self.pd == "f32" and self.E % 16 == 0
 
     def _policy_table(self, ws):
         """Per-word input side of the policy LSTM, table[w] = W_ih emb[w] + b_ih + b_hh (models.py:73, 80), and
@@ -629,8 +629,32 @@ class A2CEngine:
                 ws["h_p"], ws["h_d"] = hip.f16x2_pieces(rows, H, self.device)
                 ws["h_d"].fill_(1.0 / 4096.0)
             hip.cut_f16x2(ws["Wcat"], ws["Wcat_p"], ws["Wcat_d"])
-        hip.gemm(P["caption_embedding.weight"], P["lstm.weight_ih_l0"], ws["table_p"], bias=P["lstm.bias_ih_l0"],
-                 bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
+            # the rounds before the table is ready use the vocabulary rows of the pieces already
+            ws["ev_wcat"] = torch.cuda.Event()
+            ws["ev_wcat"].record(torch.cuda.current_stream())
+        if self._rollout_f16x2():
+            self._word_table_f16x2(ws, "p", P["caption_embedding.weight"], P["lstm.weight_ih_l0"], P["lstm.bias_ih_l0"],
+                                   P["lstm.bias_hh_l0"], ws["table_p"])
+        else:
+            hip.gemm(P["caption_embedding.weight"], P["lstm.weight_ih_l0"], ws["table_p"], bias=P["lstm.bias_ih_l0"],
+                     bias2=P["lstm.bias_hh_l0"], dtype=self.pd)
+
+    def _word_table_f16x2(self, ws, tag, emb, w_ih, bias, bias2, out):
+        """out[w] = W_ih emb[w] + bias (+ bias2) for every word on the f16 matrix instruction: both matrices are cut
+        into two scaled f16 pieces (each row by its own power of two) and multiplied by hipabi.gemm_f16x2, float32
+        rounding-level accuracy at half the exact kernel's time (a table is 21 GFLOP, built beside the first rollout
+        rounds, whose launches it slows for as long as it runs)."""
+        key = "tab16_" + tag
+        if key not in ws:
+            ws[key] = (hip.f16x2_pieces(emb.shape[0], emb.shape[1], self.device),
+                       hip.f16x2_pieces(w_ih.shape[0], w_ih.shape[1], self.device),
+                       torch.empty_like(bias))
+        (ep, ed), (wp, wd), bsum = ws[key]
+        hip.cut_f16x2(emb, ep, ed)
+        hip.cut_f16x2(w_ih, wp, wd)
+        if bias2 is not None:
+            torch.add(bias, bias2, out=bsum)
+        hip.gemm_f16x2(ep, ed, wp, wd, out, emb.shape[1], bias=bsum if bias2 is not None else bias)
 
     def _rollout(self, ws, features, n, p0, s, uniforms, mode, ev_table=None):
         """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
@@ -645,15 +669,16 @@ class A2CEngine:
         t_steps = p0 - 1 + s
         Hb, Cb, gates = ws["Hbuf"], ws["Cbuf"], ws["gates"]
         tokT, V = ws["tokT"], self.vocab
-        # h0 = cnn2linear(features): a 64-tile output with a long k, first on the step's critical path; k is
-        # split over workgroups (partial slabs summed on top of the bias)
-        Hb[0].copy_(P["cnn2linear.bias"].expand_as(Hb[0]))
-        hip.gemm_auto(features, P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True, dtype=self.pd)
+        if not ws.pop("h0_done", False):
+            self._rollout_h0(ws, features)
         fused_step = self.E % 64 == 0 and self.pd == "f32"
         mode_s = mode if mode == hip.GREEDY else mode | hip.EMIT_DLOGITS
         cell_done = False
         h_cut = False   # the newest h is already in ws["h_p"] (left there by the sampler launch that computed it)
-        for k in range(t_steps):
+        wcat_ready = False
+        k = -1
+        while k + 1 < t_steps:
+            k += 1
             if not cell_done:
                 self._rollout_cell(ws, k, n, fused_step)
             cell_done = False
@@ -673,6 +698,19 @@ class A2CEngine:
                 if self._rollout_f16x2():
                     if not h_cut:
                         hip.cut_f16x2(Hb[k + 1], ws["h_p"], ws["h_d"], fixed_scale=4096.0)
+                    if hip.PROFILE is None:
+                        # every remaining round of this kind by one call into the library (the same launches; a host
+                        # call per launch, 50 us a round, is more than the two launches take on the device)
+                        rounds = t_steps - 1 - k
+                        hip.policy_rollout_rounds(
+                            ws["Wcat_p"], ws["Wcat_d"], ws["bcat"], ws["h_p"], ws["h_d"], ext, n, V, self._padded_vocab(),
+                            rounds, mode_s, tokT[k + 1:k + 1 + rounds], ws["logp"][st:st + rounds], ws["table_p"],
+                            gates[k + 1:k + 1 + rounds], Cb[k + 1:k + 2 + rounds], Hb[k + 2:k + 2 + rounds],
+                            uniforms=None if uniforms is None else uniforms[st * n:(st + rounds) * n],
+                            probs=ws["dlogits"][st:st + rounds] if mode != hip.GREEDY else None,
+                            entropy=ws["entropy"][st:st + rounds] if (self.want_entropy and mode != hip.GREEDY) else None)
+                        k, cell_done, h_cut = t_steps - 2, True, True
+                        continue
                     hip.gemm_f16x2(ws["h_p"], ws["h_d"], ws["Wcat_p"], ws["Wcat_d"], ext, H, bias=ws["bcat"])
                     out["h_pieces"] = ws["h_p"]
                     h_cut = True
@@ -683,11 +721,28 @@ class A2CEngine:
                 cell_done = True
             else:
                 logits = ws["logits"][:n]
-                hip.gemm(Hb[k + 1], P["linear2vocab.weight"], logits, bias=P["linear2vocab.bias"], dtype=self.pd)
+                if ev_table is not None and self._rollout_f16x2() and V % 4 == 0:
+                    # (a round without the next cell update: the first ones, while the table is being built, and the last)
+                    if not wcat_ready:
+                        torch.cuda.current_stream().wait_event(ws["ev_wcat"])
+                        wcat_ready = True
+                    if not h_cut:
+                        hip.cut_f16x2(Hb[k + 1], ws["h_p"], ws["h_d"], fixed_scale=4096.0)
+                    hip.gemm_f16x2(ws["h_p"], ws["h_d"], ws["Wcat_p"], ws["Wcat_d"], logits, H, bias=ws["bcat"])
+                else:
+                    hip.gemm(Hb[k + 1], P["linear2vocab.weight"], logits, bias=P["linear2vocab.bias"], dtype=self.pd)
+                h_cut = False
                 hip.sample_tokens(logits, mode_s, tokT[k + 1], 1, **out)
         # the embedding rows of the steps that took their input side from the table are gathered when the
         # backward pass asks for them
         ws["X_pending"] = ev_table is not None
+
+    def _rollout_h0(self, ws, features):
+        """h0 = cnn2linear(features) (models.py:71): a 64-tile output with a long k, first on the step's critical
+        path; k is split over workgroups (partial slabs summed on top of the bias)."""
+        Hb = ws["Hbuf"]
+        Hb[0].copy_(self.P["cnn2linear.bias"].expand_as(Hb[0]))
+        hip.gemm_auto(features, self.P["cnn2linear.weight"], Hb[0], ws["scratch_main"], accumulate=True, dtype=self.pd)
 
     def _rollout_cell(self, ws, k, n, fused_step):
         """The policy LSTM's step k for all rows (models.py:73, 80): embedding lookup, both gate products, cell."""
@@ -924,6 +979,8 @@ class A2CEngine:
         # the side stream beside the rollout, whose small launches leave most of the device idle
         ev_start = torch.cuda.Event()
         ev_start.record(main)
+        self._rollout_h0(ws, features)   # first on the critical path: queued before the other streams' launches
+        ws["h0_done"] = True             # (for the _rollout call below)
         with torch.cuda.stream(side):
             side.wait_event(ev_start)
             hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
@@ -949,7 +1006,8 @@ class A2CEngine:
         main.wait_event(ev_tables)
         ws["policy_early"] = False
         if backward and mode != hip.GREEDY:
-            self._order_tokens(ws, n, (p0 - 1 + s) * n, main, side)
+            # (queued behind the forward chains' launch, beside which it runs: _chains_forward_loss)
+            ws["order_pending"] = (n, (p0 - 1 + s) * n)
             ws["early_pending"] = bool(self.concurrent)
         last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
@@ -1079,13 +1137,22 @@ class A2CEngine:
                                         device=self.device)
             ws["table_v"] = torch.empty(V["valrnn.caption_embedding.weight"].shape[0], 4 * H, dtype=torch.float32,
                                         device=self.device)
-        hip.gemm(V["valrnn.caption_embedding.weight"], V["valrnn.lstm.weight_ih_l0"], ws["table_v"],
-                 bias=V["valrnn.lstm.bias_ih_l0"], bias2=V["valrnn.lstm.bias_hh_l0"])
+        f16 = self.rollout_arith == "f16x2" and V["valrnn.caption_embedding.weight"].shape[1] % 16 == 0
+        if f16:
+            self._word_table_f16x2(ws, "v", V["valrnn.caption_embedding.weight"], V["valrnn.lstm.weight_ih_l0"],
+                                   V["valrnn.lstm.bias_ih_l0"], V["valrnn.lstm.bias_hh_l0"], ws["table_v"])
+        else:
+            hip.gemm(V["valrnn.caption_embedding.weight"], V["valrnn.lstm.weight_ih_l0"], ws["table_v"],
+                     bias=V["valrnn.lstm.bias_ih_l0"], bias2=V["valrnn.lstm.bias_hh_l0"])
         # a reward network declared frozen (it is, during A2C training: trainers.py:372-373) keeps its table
         # until parameters_changed() is called
         if not (self.frozen_reward and ws.get("table_r_epoch") == self._param_epoch):
-            hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["table_r"],
-                     bias=R["rewrnn.gru.bias_ih_l0"])
+            if f16 and R["rewrnn.caption_embedding.weight"].shape[1] % 16 == 0:
+                self._word_table_f16x2(ws, "r", R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"],
+                                       R["rewrnn.gru.bias_ih_l0"], None, ws["table_r"])
+            else:
+                hip.gemm(R["rewrnn.caption_embedding.weight"], R["rewrnn.gru.weight_ih_l0"], ws["table_r"],
+                         bias=R["rewrnn.gru.bias_ih_l0"])
             ws["table_r_epoch"] = self._param_epoch
 
     def _early_now(self, ws, n, p0, s, main):
@@ -1110,7 +1177,7 @@ class A2CEngine:
             self._mark("check:policy_early_done")
         ws["policy_early"], ws["ev_early"] = True, done
 
-    def _order_tokens(self, ws, n, rows, main, side):
+    def _order_tokens(self, ws, n, rows, main, side, after=None):
         """The rows of the token matrix listed by token (what the reproducible embedding gradients sum by): it
         needs the tokens only, and both trainable embedding tables are looked up with the same ones, so it is
         built once per minibatch, on the side stream, where the gradients that use it are computed later."""
@@ -1124,8 +1191,10 @@ class A2CEngine:
         # on the third stream (idle until the replay check), so that it delays neither the chains' input
         # products on the side stream nor the chains; the side stream picks the result up from there
         check = self._check_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
+        ev = after    # an event after which the tokens are final (default: everything queued on main so far)
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(main)
         with torch.cuda.stream(check):
             check.wait_event(ev)
             hip.token_order(ws["tokT"].view(-1), 1, rows, self._emb_vocab(), ws["emb_work"])
@@ -1176,19 +1245,20 @@ class A2CEngine:
         assert pair or not collapsed or (seg and seg_r), "replays are only left out on the segmented kernels"
         if rows or not pair:
             self._early_now(ws, n, p0, s, main)
+        # The device starts launches in about the order the host queues them, whatever their streams: the two
+        # gathers the chains wait for go first, and what the chains do not need (the token order for the embedding
+        # gradients, the value network's embedding rows) is queued behind the chains' launch and runs beside it
+        # (queued in front, those five small launches ran one after the other, 0.2 ms between the last sampler and
+        # the chains).
         ev_tok = torch.cuda.Event()
         ev_tok.record(main)
+        hip.gather_rows(ws["table_v"], tok_flat, 1, lv * n, ws["XPv"])
         with torch.cuda.stream(side):
             side.wait_event(ev_tok)
             hip.gather_rows(ws["table_r"], tok_flat, 1, l_cols * n, ws["XPr"])
             if pair:
                 ev_xpr = torch.cuda.Event()
                 ev_xpr.record(side)
-                if backward:
-                    # the value network's embedding rows, which only its input-side weight gradient reads: gathered
-                    # here beside the chains instead of at the end of the step (this stream's later events cover it)
-                    hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
-                    ws["Xv_gathered"] = True
             elif seg_r:
                 hip.gru_chain_fwd_seg(ws["XPr"], R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], n, p0 + 1, s,
                                       plan_r[1], plan_r[2], ws["hr"], ws["work_r"], ws["seam"][2:4], full_calls=fc,
@@ -1202,7 +1272,6 @@ class A2CEngine:
                 self._reward_head(ws, features, n, s, side, visual_done=True)
                 ev_rew = torch.cuda.Event()
                 ev_rew.record(side)
-        hip.gather_rows(ws["table_v"], tok_flat, 1, lv * n, ws["XPv"])
         if pair:
             main.wait_event(ev_xpr)
         if rows:
@@ -1234,6 +1303,14 @@ class A2CEngine:
             else:
                 self._early_now(ws, n, p0, s, main)
                 hip.chain_pair_fwd_seg(*pair_args, **pair_opts)
+        if "order_pending" in ws:
+            self._order_tokens(ws, *ws.pop("order_pending"), main, side, after=ev_tok)
+        if pair and backward:
+            # the value network's embedding rows, which only its input-side weight gradient reads: gathered
+            # beside the chains instead of at the end of the step (the side stream's later events cover it)
+            with torch.cuda.stream(side):
+                hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
+            ws["Xv_gathered"] = True
         ev_seam = None
         if pair:
             ev_seam = self._seam_to_host(ws, main)

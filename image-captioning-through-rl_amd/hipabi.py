@@ -81,6 +81,7 @@ SIGNATURES = {
                                    c_vp]),
     "icrl_sample_tokens_lstm_cell": (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                                              c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_policy_rollout_rounds": (c_int, [c_vp] * 6 + [c_i64] + [c_int] * 5 + [c_vp] * 10),
     "icrl_policy_dlogits": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp]),
     "icrl_chain_sync_bytes": (c_i64, []),
     "icrl_lstm_chain_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -416,6 +417,27 @@ def sample_tokens_lstm_cell(logits, mode, tokens_out, token_stride, pre, table, 
                                                _ptr(pre), pre.stride(0), _ptr(table), _ptr(gates_out), _ptr(c_prev),
                                                _ptr(c_out), _ptr(h_out), _ptr(h_pieces), _stream()),
            "icrl_sample_tokens_lstm_cell")
+
+
+def policy_rollout_rounds(w_pieces, w_descale, bias, h_pieces, h_descale, ext, n, v, pre_col, rounds, mode, tokens, log_prob,
+                          table, gates, c_state, h_state, *, uniforms=None, probs=None, entropy=None):
+    """`rounds` rollout rounds (gemm_f16x2 then sample_tokens_lstm_cell each) queued by one call into the library.
+    tokens [rounds, n] int64, log_prob [rounds, n], probs [rounds, n, v], entropy [rounds, n], gates [rounds, n, 2048],
+    c_state [rounds + 1, n, 512], h_state [rounds, n, 512]: contiguous slices starting at the first of these rounds."""
+    assert ext.dtype == torch.float32 and ext.stride(1) == 1 and ext.shape[0] >= n and ext.shape[1] >= pre_col + 2048
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.numel() >= rounds * n
+    for t, count in ((log_prob, rounds * n), (gates, rounds * n * 2048), (c_state, (rounds + 1) * n * 512),
+                     (h_state, rounds * n * 512), (probs, rounds * n * v), (entropy, rounds * n)):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= count)
+    assert uniforms is None or (uniforms.dtype == torch.float64 and uniforms.is_contiguous() and uniforms.numel() >= rounds * n)
+    assert table.shape == (v, 2048) and table.is_contiguous() and bias.numel() >= pre_col + 2048
+    assert w_pieces.numel() >= load().icrl_f16x2_piece_halves(pre_col + 2048, 512) and w_descale.numel() >= pre_col + 2048
+    assert h_pieces.numel() >= load().icrl_f16x2_piece_halves(n, 512) and h_descale.numel() >= n
+    _check(load().icrl_policy_rollout_rounds(_ptr(w_pieces), _ptr(w_descale), _ptr(bias), _ptr(h_pieces), _ptr(h_descale),
+                                             _ptr(ext), ext.stride(0), n, v, pre_col, rounds, mode, _ptr(uniforms),
+                                             _ptr(tokens), _ptr(log_prob), _ptr(probs), _ptr(entropy), _ptr(table),
+                                             _ptr(gates), _ptr(c_state), _ptr(h_state), _stream()),
+           "icrl_policy_rollout_rounds")
 
 
 def masked_nll(log_probs, valid_steps, row_weight, loss, d_logp=None):

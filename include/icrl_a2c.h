@@ -254,6 +254,21 @@ int icrl_sample_tokens_lstm_cell(const float* logits, int64_t ld_logits, int N, 
                                  const float* c_prev, float* c_out, float* h_out, void* h_pieces,
                                  icrl_stream_t stream);
 
+/* `rounds` consecutive rollout rounds (models.py:73-82 one column at a time; trainers.py:443-458) queued by one call:
+ * round r multiplies the newest h (in h_pieces, where the round before left it; the caller cuts the first one) by
+ * the pieces of [linear2vocab.weight (rows padded to pre_col) ; lstm.weight_hh] with icrl_gemm_f16x2 into
+ * ext [N, pre_col + 2048] (row stride ld_ext), then runs icrl_sample_tokens_lstm_cell on it: token, log-probability,
+ * optional probabilities / entropy, and the next cell update.  Arrays advance by one round per round: uniforms,
+ * tokens, log_prob, entropy by N; probs by N V; gates (receives the next cell's activated gates) by N 2048; c_state
+ * holds the cell state the round starts from at r N 512 and receives the next at (r + 1) N 512; h_state receives the
+ * next h at r N 512.  Exactly the launches the caller would queue one by one, without a host call per launch (at 25
+ * + 20 us per round the host, not the device, was what paced the rollout). */
+int icrl_policy_rollout_rounds(const void* w_pieces, const float* w_descale, const float* bias, void* h_pieces,
+                               const float* h_descale, float* ext, int64_t ld_ext, int N, int V, int pre_col,
+                               int rounds, int mode, const double* uniforms, int64_t* tokens, float* log_prob,
+                               float* probs, float* entropy, const float* table, float* gates,
+                               const float* c_state, float* h_state, icrl_stream_t stream);
+
 /* values[r, 0..k) / indices[r, 0..k) = the k largest entries of logits[r, 0..V) in descending order,
  * ties by lowest index: torch.topk(output[:, -1:, :], beamSize) of the look-ahead decoder,
  * trainers.py:96.  k <= 64, V <= 16384. */
