@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--policy-dtype", default="f32", choices=("f32", "bf16"),
                     help="bf16: the policy network's products on the bf16 matrix instruction (NOT the headline "
                          "workload's arithmetic: reported under its own workload name and dtype)")
-    ap.add_argument("--grad-products", default=None, choices=("f32", "f32x3"),
+    ap.add_argument("--grad-products", default=None, choices=("f32", "f32x3", "f16x2"),
                     help="how the backward pass forms its products over all positions (default: the engine's)")
     ap.add_argument("--value-forget-bias", type=float, default=0.0,
                     help="added to the value LSTM's forget-gate bias: a recurrence with a longer memory (stress case, "

@@ -1227,6 +1227,8 @@ struct HpArgs {
     float* saved; float* h_emit; float* seam_a; float* seam_b;
     unsigned* flags;          // [row groups][32]
     Geom g;
+    const float* state_in;    // {h, c} (GRU: {h}) the chains start from (loaded at position -1), or null
+    int state_stride;         // floats between the start states of consecutive segments
 };
 
 __device__ __forceinline__ void split2h(float x, _Float16& hi, _Float16& mid) {
@@ -1367,8 +1369,16 @@ __device__ __forceinline__ void hp_chain(const HpArgs& a, int bx, int by, unsign
 
         if (st != 0) {
             float2 h = make_float2(0.f, 0.f);
+            // where a segment's final state is recorded: with the next segment's seam, or (segments that all
+            // replay the same positions) under its own index
+            const int rec = g.stride == 0 ? j : j + 1;
             if (st == 1) {
                 state = make_float2(0.f, 0.f);
+                if (a.state_in != nullptr && pos == -1) {   // the step before the chain's first position
+                    const float* si = a.state_in + (int64_t)j * a.state_stride;
+                    h = *reinterpret_cast<const float2*>(si + u);
+                    state = (G == 4) ? *reinterpret_cast<const float2*>(si + H + u) : h;
+                }
             } else {
                 const float* pr = gt + rr * WGT + uq;
                 if (G == 4) {
@@ -1385,7 +1395,7 @@ __device__ __forceinline__ void hp_chain(const HpArgs& a, int bx, int by, unsign
                         ST2(sp, gi); ST2(sp + H, gf); ST2(sp + 2 * H, gg); ST2(sp + 3 * H, go); ST2(sp + 4 * H, c); ST2(sp + 5 * H, h);
                     }
                     if (qs == -1) ST2(a.seam_a + (int64_t)j * 2 * H + H + u, c);
-                    if (qs == g.Ls - 1 && j + 1 < g.K) ST2(a.seam_b + (int64_t)(j + 1) * 2 * H + H + u, c);
+                    if (qs == g.Ls - 1 && rec < g.K) ST2(a.seam_b + (int64_t)rec * 2 * H + H + u, c);
                 } else {
                     const float2 hr_ = make_float2(pr[0] + bias[0].x, pr[1] + bias[0].y);
                     const float2 hz = make_float2(pr[32 * WGT] + bias[1].x, pr[32 * WGT + 1] + bias[1].y);
@@ -1404,7 +1414,7 @@ __device__ __forceinline__ void hp_chain(const HpArgs& a, int bx, int by, unsign
                 if (qs >= 0 && a.h_emit != nullptr && pt == g.p0 + ps - 1) ST2(a.h_emit + ((int64_t)ps * g.n + pi) * H + u, h);
                 constexpr int SW = (G == 4) ? 2 * H : H;  // seam record: {h, c} or {h}
                 if (qs == -1) ST2(a.seam_a + (int64_t)j * SW + u, h);
-                if (qs == g.Ls - 1 && j + 1 < g.K) ST2(a.seam_b + (int64_t)(j + 1) * SW + u, h);
+                if (qs == g.Ls - 1 && rec < g.K) ST2(a.seam_b + (int64_t)rec * SW + u, h);
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, h), rs, (j * H + u) * 4, nxt * g.K * H * 4, SC1);
         }
@@ -1423,8 +1433,16 @@ __global__ __launch_bounds__(256, 2) void seg_fwd_pair_hp(HpArgs v, HpArgs r, un
     extern __shared__ __attribute__((aligned(16))) char hp_lds[];
     __builtin_amdgcn_s_setprio(3);
     const int chain = blockIdx.x / per_chain, w = blockIdx.x % per_chain;
-    const int xcd = w & 7, t = w >> 3;
-    const int by = (t >> 5) * 8 + xcd, bx = t & 31;
+    int by, bx;
+    if (ny < 8) {
+        // fewer than eight row groups (the replay check's single one): consecutive block ids, which the dispatcher
+        // deals out over all XCDs.  Packed into one XCD they fill its CUs' registers, and a persistent launch of
+        // another stream that needs a CU there for one of its workgroups (the value chain's BPTT) cannot start
+        by = w >> 5; bx = w & 31;
+    } else {
+        const int xcd = w & 7, t = w >> 3;
+        by = (t >> 5) * 8 + xcd; bx = t & 31;
+    }
     if (by >= ny) return;
     if (chain == 0) hp_chain<4>(v, bx, by, abort_w, hp_lds);
     else hp_chain<3>(r, bx, by, abort_w, hp_lds);
@@ -2274,7 +2292,7 @@ int pair_hp(HpArgs& v, HpArgs& r, float* work_v, float* work_r, hipStream_t st, 
     v.hb = work_v; v.seam_a = work_v + 4 * kh; v.seam_b = work_v + 6 * kh; v.flags = words;
     r.hb = work_r; r.seam_a = work_r + 2 * kh; r.seam_b = work_r + 3 * kh; r.flags = words + ny * 32;
     *abort_out = words + 2 * ny * 32;
-    const int per_chain = (ny + 7) / 8 * 8 * 32;
+    const int per_chain = ny < 8 ? ny * 32 : (ny + 7) / 8 * 8 * 32;
     hipLaunchKernelGGL(seg_fwd_pair_hp, dim3(2 * per_chain), dim3(256), WARM_LDS, st, v, r, *abort_out, per_chain, ny);
     return ICRL_OK;
 }
@@ -2797,25 +2815,25 @@ void replay_geom(Geom& g, int N, int rows, int steps) {
 }
 }  // namespace
 
-extern "C" int icrl_chain_pair_replay_check(const float* xproj_v, const float* w_hh_v, const float* saved_v,
-                                            const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
-                                            const float* saved_r, int N, int p0_v, int p0_r, int n_calls,
-                                            int full_calls, int steps, float* work_v, float* work_r, float* err,
-                                            icrl_stream_t stream) {
-    ICRL_REQUIRE(N > 0 && p0_v > 0 && p0_r > 0 && n_calls > 1, "icrl_chain_pair_replay_check: bad shape");
+namespace {
+int replay_check(const char* who, bool f16x2, const float* xproj_v, const float* w_hh_v, const float* saved_v,
+                 const float* xproj_r, const float* w_hh_r, const float* b_hh_r, const float* saved_r, int N, int p0_v,
+                 int p0_r, int n_calls, int full_calls, int steps, float* work_v, float* work_r, float* err,
+                 icrl_stream_t stream) {
+    ICRL_REQUIRE(N > 0 && p0_v > 0 && p0_r > 0 && n_calls > 1, "%s: bad shape", who);
     ICRL_REQUIRE(full_calls >= 1 && full_calls < n_calls,
-                 "icrl_chain_pair_replay_check: full_calls must be in [1, n_calls): nothing is left out otherwise");
+                 "%s: full_calls must be in [1, n_calls): nothing is left out otherwise", who);
     const int rows = n_calls - full_calls;
     const int64_t len_v = (int64_t)(p0_v + full_calls - 1) * N, len_r = (int64_t)(p0_r + full_calls - 1) * N;
     ICRL_REQUIRE(steps >= 1 && steps <= len_v && steps <= len_r,
-                 "icrl_chain_pair_replay_check: steps must be in [1, %lld], the length of the shortest replay left out",
+                 "%s: steps must be in [1, %lld], the length of the shortest replay left out", who,
                  (long long)std::min(len_v, len_r));
     ICRL_REQUIRE(xproj_v && w_hh_v && saved_v && xproj_r && w_hh_r && b_hh_r && saved_r && work_v && work_r && err,
-                 "icrl_chain_pair_replay_check: null pointer");
+                 "%s: null pointer", who);
     ICRL_REQUIRE(aligned16(xproj_v) && aligned16(w_hh_v) && aligned16(saved_v) && aligned16(xproj_r) &&
                  aligned16(w_hh_r) && aligned16(b_hh_r) && aligned16(saved_r) && aligned16(work_v) && aligned16(work_r),
-                 "icrl_chain_pair_replay_check: buffers must be 16-byte aligned");
-    ICRL_REQUIRE(icrl_chain_pair_supported(rows), "icrl_chain_pair_replay_check: too many rows for this device");
+                 "%s: buffers must be 16-byte aligned", who);
+    ICRL_REQUIRE(icrl_chain_pair_supported(rows), "%s: too many rows for this device", who);
     hipStream_t st = icrl::as_stream(stream);
     ChainArgs v{}, r{};
     replay_geom(v.g, N, rows, steps);
@@ -2834,7 +2852,14 @@ extern "C" int icrl_chain_pair_replay_check(const float* xproj_v, const float* w
     v.xproj = xproj_v; v.w_hh = w_hh_v; v.state_in = states_v; v.state_stride = 2 * H;
     r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.state_in = states_r; r.state_stride = H;
     unsigned* abort_w = nullptr;
-    if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
+    if (f16x2) {   // the same replays in the f16 launch (what the chains themselves were walked with)
+        ICRL_REQUIRE(icrl_chain_f16x2_supported(rows), "%s: too many rows for this device", who);
+        HpArgs hv{}, hr{};
+        hv.xproj = xproj_v; hv.w_hh = w_hh_v; hv.b_hh = nullptr; hv.g = v.g; hv.state_in = states_v; hv.state_stride = 2 * H;
+        hr.xproj = xproj_r; hr.w_hh = w_hh_r; hr.b_hh = b_hh_r; hr.g = r.g; hr.state_in = states_r; hr.state_stride = H;
+        if (int rc = pair_hp(hv, hr, work_v, work_r, st, &abort_w, nullptr, nullptr)) return rc;
+        v.seam_b = hv.seam_b; r.seam_b = hr.seam_b;
+    } else if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
     // the state the last fully walked call had after the same `steps` inputs
     const int64_t target_v = ((int64_t)c0_v - (p0_v + full_calls - 1)) * N + steps - 1;
     const int64_t target_r = ((int64_t)c0_r - (p0_r + full_calls - 1)) * N + steps - 1;
@@ -2845,6 +2870,25 @@ extern "C" int icrl_chain_pair_replay_check(const float* xproj_v, const float* w
     hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, err, err + 1);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
+}
+}  // namespace
+
+extern "C" int icrl_chain_pair_replay_check(const float* xproj_v, const float* w_hh_v, const float* saved_v,
+                                            const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
+                                            const float* saved_r, int N, int p0_v, int p0_r, int n_calls,
+                                            int full_calls, int steps, float* work_v, float* work_r, float* err,
+                                            icrl_stream_t stream) {
+    return replay_check("icrl_chain_pair_replay_check", false, xproj_v, w_hh_v, saved_v, xproj_r, w_hh_r, b_hh_r, saved_r, N,
+                        p0_v, p0_r, n_calls, full_calls, steps, work_v, work_r, err, stream);
+}
+
+extern "C" int icrl_chain_pair_replay_check_f16x2(const float* xproj_v, const float* w_hh_v, const float* saved_v,
+                                                  const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
+                                                  const float* saved_r, int N, int p0_v, int p0_r, int n_calls,
+                                                  int full_calls, int steps, float* work_v, float* work_r, float* err,
+                                                  icrl_stream_t stream) {
+    return replay_check("icrl_chain_pair_replay_check_f16x2", true, xproj_v, w_hh_v, saved_v, xproj_r, w_hh_r, b_hh_r, saved_r,
+                        N, p0_v, p0_r, n_calls, full_calls, steps, work_v, work_r, err, stream);
 }
 
 // ------------------------------------------------------------------ every row its own chain

@@ -15,19 +15,30 @@
 // registers; LDS rows of k as in gemm_bf16.hip, three images per operand, one stage at a time: 36 KB per
 // workgroup, so that four fit a CU and two fit beside a persistent chain workgroup (which leaves 76-80 KB).  With
 // 32-deep stages (60 KB) the same loop ran 5-15 % slower at two per CU and 1.4 times slower where only one fits.
+//
+// NP = 2 is the same kernel on two f16 pieces (icrl_gemm_f16x2s): every row of A and of B (as the product sees them:
+// one per output row / column) is scaled by a power of two the caller supplies - its largest entry in [2^14, 2^15),
+// see icrl_absmax_scales - and cut into hi + mid, x s = hi + mid to 2^-22 of the element wherever both are normal
+// f16 numbers (entries within 2^-18 of the row's largest; smaller ones keep an absolute error of 2^-40 of the
+// largest).  An element product is hi.hi + hi.mid + mid.hi on v_mfma_f32_32x32x16_f16, three instructions instead of
+// six, two LDS images instead of three (24 KB a stage), and the epilogue divides the scales out again (exactly).
+// 1.45-1.6 times the three-piece kernel's rate on the backward pass's shapes, same accuracy class (2^-21 per element
+// product against 2^-23: below the float32 rounding of the 10^4-term sums these products are).
 #include "icrl_common.h"
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short lds_t;   // a bf16 (NP = 3) or f16 (NP = 2) piece
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 constexpr int LDK = BK + 8;   // bf16 elements per LDS row (12 dwords: the ds_read_b128 of 16 rows at one k offset is conflict-free)
 constexpr int BM = 128, BN = 128, NT = 256;
 constexpr int A_PLANE = BM * LDK, B_PLANE = BN * LDK;      // one piece's image of an operand tile (bf16 elements)
-constexpr int BUF = 3 * (A_PLANE + B_PLANE);               // one stage: A hi, mid, lo, B hi, mid, lo (36 KB)
+constexpr int BUF = 3 * (A_PLANE + B_PLANE);               // one stage: A hi, mid, lo, B hi, mid, lo (36 KB; 24 KB of it with two pieces)
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -47,6 +58,16 @@ __device__ __forceinline__ void split3(float x, float y, unsigned& hi, unsigned&
     lo = pack2(sx, sy);
 }
 
+// x = hi + mid + r, |r| <= 2^-22 |x|, two f16 pieces (x already scaled into f16's range)
+__device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& mid) {
+    typedef _Float16 hf16x2 __attribute__((ext_vector_type(2)));
+    hf16x2 h, m;
+    h[0] = (_Float16)x; h[1] = (_Float16)y;
+    m[0] = (_Float16)(x - (float)h[0]); m[1] = (_Float16)(y - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    mid = __builtin_bit_cast(unsigned, m);
+}
+
 // Staging of one operand tile of ROWS x BK: global -> registers (load), registers -> three LDS images [row][k]
 // `plane` elements apart (store3).
 // KM = false (k contiguous in memory, [rows][ld]): piece i of thread tid is row f / 4, k quad f % 4, f = tid + NT i:
@@ -60,6 +81,15 @@ struct Stage {
     static constexpr int PIECES = KM ? ROWS * BK / 8 / NT : ROWS * BK / 4 / NT;
     static_assert(PIECES >= 1 && PIECES * NT * (KM ? 8 : 4) == ROWS * BK, "the tile divides among the threads");
     float x[PIECES][KM ? 8 : 4];
+    float sc[PIECES];   // NP = 2: the power-of-two scale of each piece's row (a piece's row is the same in every stage)
+
+    __device__ __forceinline__ void scales(const float* s, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int f = tid + NT * i;
+            sc[i] = s[min(row0 + (KM ? f % ROWS : f / (BK / 4)), nrows - 1)];
+        }
+    }
 
     // EDGE = false: whole k stages and (KM = false) aligned float4: plain loads, no branches.  Rows past the matrix'
     // last one read the last row again (the epilogue does not store their products), so that a ragged last tile row
@@ -88,36 +118,43 @@ struct Stage {
         }
     }
 
-    __device__ __forceinline__ void store3(__bf16* lds, int plane, int tid) const {
+    template <int NP>
+    __device__ __forceinline__ void store(lds_t* lds, int plane, int tid) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int f = tid + NT * i;
             if (!KM) {
                 uint2 w[3];
-                split3(x[i][0], x[i][1], w[0].x, w[1].x, w[2].x);
-                split3(x[i][2], x[i][3], w[0].y, w[1].y, w[2].y);
-                __bf16* dst = lds + (f / (BK / 4)) * LDK + 4 * (f % (BK / 4));
+                if (NP == 3) {
+                    split3(x[i][0], x[i][1], w[0].x, w[1].x, w[2].x);
+                    split3(x[i][2], x[i][3], w[0].y, w[1].y, w[2].y);
+                } else {
+                    split2(x[i][0] * sc[i], x[i][1] * sc[i], w[0].x, w[1].x);
+                    split2(x[i][2] * sc[i], x[i][3] * sc[i], w[0].y, w[1].y);
+                }
+                lds_t* dst = lds + (f / (BK / 4)) * LDK + 4 * (f % (BK / 4));
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = w[p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(dst + p * plane) = w[p];
             } else {
                 u32x4 w[3];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    unsigned hi, mid, lo;
-                    split3(x[i][2 * e], x[i][2 * e + 1], hi, mid, lo);
+                    unsigned hi, mid, lo = 0;
+                    if (NP == 3) split3(x[i][2 * e], x[i][2 * e + 1], hi, mid, lo);
+                    else split2(x[i][2 * e] * sc[i], x[i][2 * e + 1] * sc[i], hi, mid);
                     w[0][e] = hi; w[1][e] = mid; w[2][e] = lo;
                 }
-                __bf16* dst = lds + (f % ROWS) * LDK + 8 * (f / ROWS);
+                lds_t* dst = lds + (f % ROWS) * LDK + 8 * (f / ROWS);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst + p * plane) = w[p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * plane) = w[p];
             }
         }
     }
 };
 
 // Fragment of lane (r = lane & 31, h = lane >> 5) for k-step s of 16: elements k = 16 s + 8 h + j, j = 0..7 of row r
-__device__ __forceinline__ bf16x8 frag(const __bf16* lds, int row, int kstep, int h) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + row * LDK + 8 * (2 * kstep + h)));
+__device__ __forceinline__ u32x4 frag(const lds_t* lds, int row, int kstep, int h) {
+    return *reinterpret_cast<const u32x4*>(lds + row * LDK + 8 * (2 * kstep + h));
 }
 
 struct GemmArgs {
@@ -129,10 +166,12 @@ struct GemmArgs {
     int accumulate;
     int kchunk;        // k-range per split (split-K); a multiple of BK
     int64_t slab;      // C offset (floats) between split-K partial results
+    const float* sa;   // NP = 2: power-of-two scale of every row of A (M entries) and of B (N entries)
+    const float* sb;
 };
 
-template <bool A_KM, bool B_KM, bool EDGE>
-__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], __bf16* lds, int m0, int n0, int kbeg,
+template <int NP, bool A_KM, bool B_KM, bool EDGE>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], lds_t* lds, int m0, int n0, int kbeg,
                                        int kend, int nk, int tid) {
     constexpr int DEPTH = 4;   // stages in flight in registers
     const int lane = tid & 63, wave = tid >> 6;
@@ -140,6 +179,13 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], _
     const int l31 = lane & 31, h = lane >> 5;
     Stage<BM, A_KM> sa[DEPTH];
     Stage<BN, B_KM> sb[DEPTH];
+    if (NP == 2) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            sa[d].scales(g.sa, m0, g.M, tid);
+            sb[d].scales(g.sb, n0, g.N, tid);
+        }
+    }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (d < nk) {
@@ -154,11 +200,11 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], _
         for (int d = 0; d < DEPTH; ++d) {
             const int kt = kt0 + d;
             if (kt < nk) {
-                const __bf16* la = lds;
-                const __bf16* lb = la + 3 * A_PLANE;
+                const lds_t* la = lds;
+                const lds_t* lb = la + NP * A_PLANE;
                 if (kt > 0) __syncthreads();
-                sa[d].store3(lds, A_PLANE, tid);
-                sb[d].store3(lds + 3 * A_PLANE, B_PLANE, tid);
+                sa[d].template store<NP>(lds, A_PLANE, tid);
+                sb[d].template store<NP>(lds + NP * A_PLANE, B_PLANE, tid);
                 if (kt + DEPTH < nk) {
                     sa[d].template load<EDGE>(g.A, g.lda, m0, g.M, kbeg + (kt + DEPTH) * BK, kend, tid);
                     sb[d].template load<EDGE>(g.B, g.ldb, n0, g.N, kbeg + (kt + DEPTH) * BK, kend, tid);
@@ -166,35 +212,42 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], _
                 __syncthreads();
 #pragma unroll
                 for (int ks = 0; ks < BK / 16; ++ks) {
-                    bf16x8 av[2][3], bv[2][3];
+                    u32x4 av[2][NP], bv[2][NP];
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int p = 0; p < 3; ++p)
+                        for (int p = 0; p < NP; ++p)
                             av[i][p] = frag(la + p * A_PLANE, wr * 64 + i * 32 + l31, ks, h);
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int p = 0; p < 3; ++p)
+                        for (int p = 0; p < NP; ++p)
                             bv[j][p] = frag(lb + p * B_PLANE, wc * 64 + j * 32 + l31, ks, h);
                     // piece products, smallest first: (a piece, b piece) with piece 0 = hi, 1 = mid, 2 = lo
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                    constexpr int NQ = NP == 3 ? 6 : 3;
+                    constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
+                    constexpr int PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
 #pragma unroll
-                    for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][PA[q]], bv[j][PB[q]], acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < 2; ++j) {
+                                if (NP == 3)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                        __builtin_bit_cast(bf16x8, av[i][PA[q]]), __builtin_bit_cast(bf16x8, bv[j][PB[q]]), acc[i][j], 0, 0, 0);
+                                else
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                        __builtin_bit_cast(hf16x8, av[i][PA[q]]), __builtin_bit_cast(hf16x8, bv[j][PB[q]]), acc[i][j], 0, 0, 0);
+                            }
                 }
             }
         }
     }
 }
 
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[BUF];
+template <int NP, bool A_KM, bool B_KM>
+__device__ __forceinline__ void gemm_pieces(const GemmArgs& g, lds_t* lds) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -246,13 +299,13 @@ __global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
     const bool interior = aligned;   // (ragged tile rows and columns included: Stage::load)
     const int full = (kend - kbeg) / BK;
     if (interior && full > 0) {
-        k_loop<A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
+        k_loop<NP, A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
         if (full < nk) {
             __syncthreads();
-            k_loop<A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
+            k_loop<NP, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
         }
     } else if (nk > 0) {
-        k_loop<A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
+        k_loop<NP, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
@@ -263,12 +316,13 @@ __global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
             const int col = n0 + wc * 64 + j * 32 + l31;
             if (col >= g.N) continue;
             const float badd = (g.bias && split == 0) ? g.bias[col] : 0.f;
+            const float db = NP == 2 ? 1.f / g.sb[col] : 1.f;   // (powers of two: exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < g.M) {
                     float* dst = Cout + (int64_t)row * g.ldc + col;
-                    float v = acc[i][j][r] + badd;
+                    float v = (NP == 2 ? acc[i][j][r] * (1.f / g.sa[row]) * db : acc[i][j][r]) + badd;
                     if (g.accumulate) v += *dst;
                     *dst = v;
                 }
@@ -277,16 +331,29 @@ __global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
 }
 
 template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NT) void gemm_f32x3_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) lds_t lds[BUF];
+    gemm_pieces<3, A_KM, B_KM>(g, lds);
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(NT) void gemm_f16x2s_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) lds_t lds[2 * (A_PLANE + B_PLANE)];
+    gemm_pieces<2, A_KM, B_KM>(g, lds);
+}
+
+template <bool A_KM, bool B_KM>
 int launch_one(const GemmArgs& g, int splits, hipStream_t st) {
     const dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * splits);
-    hipLaunchKernelGGL((gemm_f32x3_kernel<A_KM, B_KM>), grid, dim3(NT), 0, st, g);
+    if (g.sa) hipLaunchKernelGGL((gemm_f16x2s_kernel<A_KM, B_KM>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32x3_kernel<A_KM, B_KM>), grid, dim3(NT), 0, st, g);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
 
 int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
              int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int splits, int64_t slab, int tile,
-             hipStream_t st, const char* who) {
+             hipStream_t st, const char* who, const float* sa = nullptr, const float* sb = nullptr) {
     ICRL_REQUIRE(tile == 0 || tile == 1, "%s: tile must be 0 or 1 (128x128)", who);
     ICRL_REQUIRE(A && B && C, "%s: null operand", who);
     ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty shape %dx%dx%d", who, M, N, K);
@@ -299,6 +366,7 @@ int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t 
     const int ksteps = (K + BK - 1) / BK;
     g.kchunk = ((ksteps + splits - 1) / splits) * BK;
     g.slab = slab;
+    g.sa = sa; g.sb = sb;
     if (!a_kmajor && !b_kmajor) return launch_one<false, false>(g, splits, st);
     if (!a_kmajor && b_kmajor) return launch_one<false, true>(g, splits, st);
     if (a_kmajor && !b_kmajor) return launch_one<true, false>(g, splits, st);
@@ -322,4 +390,21 @@ extern "C" int icrl_gemm_f32x3_splitk(const float* A, int64_t lda, int a_kmajor,
     ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f32x3_splitk: slabs overlap");
     return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, 0, splits, slab_stride, tile,
                     icrl::as_stream(stream), "icrl_gemm_f32x3_splitk");
+}
+
+extern "C" int icrl_gemm_f16x2s(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B, int64_t ldb,
+                                int b_kmajor, const float* b_scale, float* C, int64_t ldc, int M, int N, int K,
+                                const float* bias, int accumulate, icrl_stream_t stream) {
+    ICRL_REQUIRE(a_scale && b_scale, "icrl_gemm_f16x2s: null scale vector");
+    return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias, accumulate, 1, 0, 0,
+                    icrl::as_stream(stream), "icrl_gemm_f16x2s", a_scale, b_scale);
+}
+
+extern "C" int icrl_gemm_f16x2s_splitk(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B,
+                                       int64_t ldb, int b_kmajor, const float* b_scale, float* C_slabs, int64_t ldc,
+                                       int64_t slab_stride, int M, int N, int K, int splits, icrl_stream_t stream) {
+    ICRL_REQUIRE(a_scale && b_scale, "icrl_gemm_f16x2s_splitk: null scale vector");
+    ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f16x2s_splitk: slabs overlap");
+    return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, 0, splits, slab_stride, 0,
+                    icrl::as_stream(stream), "icrl_gemm_f16x2s_splitk", a_scale, b_scale);
 }

@@ -850,3 +850,96 @@ extern "C" int icrl_chain_hprev(const float* saved, int64_t positions, int gru, 
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Power-of-two scales for icrl_gemm_f16x2s: per row and / or per column of x, the scale that brings the largest
+// magnitude of that row / column into [2^14, 2^15).
+namespace {
+
+// bits: float bits of non-negative maxima (monotonic as unsigned integers), zeroed by the caller
+__global__ __launch_bounds__(256) void absmax2d_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols,
+                                                       unsigned* __restrict__ rowbits, unsigned* __restrict__ colbits) {
+    // workgroup: 64 rows x 256 columns; wave w takes rows w, w + 4, ...; lane l columns 4 l .. 4 l + 3 (one 16-byte load)
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + 4 * lane;
+    const int r_end = min(rows, (int)(blockIdx.y + 1) * 64);
+    const bool vec = cols % 4 == 0 && ld % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = blockIdx.y * 64 + wave; r < r_end; r += 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = x + (int64_t)r * ld + c;
+        if (vec) {
+            if (c < cols) v = *reinterpret_cast<const float4*>(p);
+        } else {
+            if (c + 0 < cols) v.x = p[0];
+            if (c + 1 < cols) v.y = p[1];
+            if (c + 2 < cols) v.z = p[2];
+            if (c + 3 < cols) v.w = p[3];
+        }
+        v.x = fabsf(v.x); v.y = fabsf(v.y); v.z = fabsf(v.z); v.w = fabsf(v.w);
+        cm.x = fmaxf(cm.x, v.x); cm.y = fmaxf(cm.y, v.y); cm.z = fmaxf(cm.z, v.z); cm.w = fmaxf(cm.w, v.w);
+        if (rowbits) {
+            const float rm = icrl::wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            if (lane == 0) atomicMax(rowbits + r, __float_as_uint(rm));
+        }
+    }
+    if (!colbits) return;
+    red[wave][lane] = cm;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 o = red[w][lane];
+            cm.x = fmaxf(cm.x, o.x); cm.y = fmaxf(cm.y, o.y); cm.z = fmaxf(cm.z, o.z); cm.w = fmaxf(cm.w, o.w);
+        }
+        atomicMax(colbits + c + 0, __float_as_uint(cm.x));
+        if (c + 1 < cols) atomicMax(colbits + c + 1, __float_as_uint(cm.y));
+        if (c + 2 < cols) atomicMax(colbits + c + 2, __float_as_uint(cm.z));
+        if (c + 3 < cols) atomicMax(colbits + c + 3, __float_as_uint(cm.w));
+    }
+}
+
+__device__ __forceinline__ float scale_for(float top) {
+    int ex = 0;
+    if (top > 0.f && top < INFINITY) frexpf(top, &ex);   // top = f 2^ex, f in [0.5, 1)
+    ex = max(-60, min(60, ex));
+    return ldexpf(1.f, 15 - ex);                          // top * scale in [2^14, 2^15)
+}
+
+__global__ void scales_from_bits_kernel(const unsigned* __restrict__ bits, int count, float* __restrict__ scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) scale[i] = scale_for(__uint_as_float(bits[i]));
+}
+
+// rows of G0 = onehot(token) - softmax: the largest magnitude of a row is its token entry, 1 - p_token (every other
+// entry is a probability, and together they sum to 1 - p_token), known from the row's log-probability alone
+__global__ void g0_row_scales_kernel(const float* __restrict__ log_prob, int count, float* __restrict__ scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) scale[i] = scale_for(fmaxf(-expm1f(log_prob[i]), 0x1p-22f) * 1.0001f);
+}
+
+}  // namespace
+
+extern "C" int icrl_absmax_scales(const float* x, int64_t ld, int rows, int cols, float* row_scale, float* col_scale,
+                                  unsigned* work, icrl_stream_t stream) {
+    ICRL_REQUIRE(x && work && (row_scale || col_scale), "icrl_absmax_scales: null pointer");
+    ICRL_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "icrl_absmax_scales: %d x %d (ld %lld)", rows, cols, (long long)ld);
+    hipStream_t st = icrl::as_stream(stream);
+    unsigned* rowbits = row_scale ? work : nullptr;
+    unsigned* colbits = col_scale ? work + (row_scale ? rows : 0) : nullptr;
+    ICRL_HIP(hipMemsetAsync(work, 0, sizeof(unsigned) * ((row_scale ? rows : 0) + (col_scale ? cols : 0)), st));
+    hipLaunchKernelGGL(absmax2d_kernel, dim3((cols + 255) / 256, (rows + 63) / 64), dim3(256), 0, st, x, ld, rows, cols, rowbits,
+                       colbits);
+    if (row_scale) hipLaunchKernelGGL(scales_from_bits_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, rowbits, rows, row_scale);
+    if (col_scale) hipLaunchKernelGGL(scales_from_bits_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, colbits, cols, col_scale);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+extern "C" int icrl_g0_row_scales(const float* log_prob, int count, float* scale, icrl_stream_t stream) {
+    ICRL_REQUIRE(log_prob && scale && count > 0, "icrl_g0_row_scales: null pointer or empty");
+    hipLaunchKernelGGL(g0_row_scales_kernel, dim3((count + 255) / 256), dim3(256), 0, icrl::as_stream(stream), log_prob, count, scale);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}

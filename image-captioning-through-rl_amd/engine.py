@@ -186,7 +186,7 @@ class A2CEngine:
                  reward_grads=None,
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
-                 frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f32x3", late_policy_bptt=True,
+                 frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f16x2", late_policy_bptt=True,
                  chain_arith="f16x2", rollout_arith="f16x2",
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
@@ -213,7 +213,9 @@ class A2CEngine:
         # G0^T . Hs, two fifths of the step's GEMM work) and the recurrent layers' weight and input gradients:
         # "f32x3" forms them from bf16 pieces of the operands at f32 rounding-level accuracy (hipabi.gemm); what
         # the forward pass computes (tokens, log-probabilities, values, rewards, the loss) stays on the exact kernel
-        assert grad_products in ("f32", "f32x3")
+        # "f16x2": the same products from two f16 pieces of the operands, each row (as the product sees it) scaled by its
+        # own power of two: half the matrix instructions of "f32x3", 1.4-1.5 times its rate, same accuracy class
+        assert grad_products in ("f32", "f32x3", "f16x2")
         self.gd = grad_products                                               # value network
         self.vgd = grad_products if policy_dtype == "f32" else policy_dtype   # policy network
         # frozen_reward: the caller promises not to write to the reward network's parameters between steps
@@ -671,6 +673,7 @@ class A2CEngine:
         tokT, V = ws["tokT"], self.vocab
         if not ws.pop("h0_done", False):
             self._rollout_h0(ws, features)
+        ws["rollout_id"] = ws.get("rollout_id", 0) + 1   # (what is derived from this rollout's outputs is kept under it)
         fused_step = self.E % 64 == 0 and self.pd == "f32"
         mode_s = mode if mode == hip.GREEDY else mode | hip.EMIT_DLOGITS
         cell_done = False
@@ -1029,8 +1032,9 @@ class A2CEngine:
             if pv[0] == "exact":
                 bi = last
             tail = with_bwd and self._tail_ok(n, pv, pr, pb)
-            if tail:
-                ws.pop("early_pending", None)   # G0 . W is formed beside the value chain's BPTT, not beside the forward chains
+            # (G0 . W is queued behind the forward chains' launch on the third stream whichever way the policy LSTM's
+            # BPTT is run: it starts when the chains end, beside the heads and the loss, and what flows into the LSTM
+            # outputs is ready when the value chain's BPTT is)
             ev_seam, ev_replay, replay_steps = self._chains_forward_loss(ws, features, n, p0, s, fc, backward, main, side,
                                                                          pv, pr)
             if with_bwd:
@@ -1170,12 +1174,27 @@ class A2CEngine:
         with torch.cuda.stream(stream):
             stream.wait_event(ev)
             G0 = ws["dlogits"].view(s * n, self.vocab)   # left by the rollout's sampler launches
-            hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ws["scratch_check"], b_kmajor=True, shared=True,
-                          dtype=self.vgd)
+            self._uvocab(ws, G0, ws["scratch_check"])
             done = torch.cuda.Event()
             done.record(stream)
             self._mark("check:policy_early_done")
         ws["policy_early"], ws["ev_early"] = True, done
+
+    def _uvocab(self, ws, G0, scratch):
+        """ws["Uvocab"] = G0 . linear2vocab.weight on the current stream (what flows into the LSTM outputs, up to the
+        per-row coefficient)."""
+        rows = self._g0_scales(ws, G0, False)[0] if self.vgd == "f16x2" else None
+        self._pgemm(ws, "uvoc", G0, self.P["linear2vocab.weight"], ws["Uvocab"], scratch, self.vgd, b_kmajor=True, shared=True,
+                    a_scale=rows)
+
+    def _vocab_weight_grad(self, ws, G0, scratch):
+        """linear2vocab.weight's gradient G0^T . (coef * Hs) on the current stream."""
+        colsc = None
+        if self.vgd == "f16x2":
+            _, colsc, ev = self._g0_scales(ws, G0, True)
+            torch.cuda.current_stream().wait_event(ev)   # (they may have been computed on another stream, beside the chains)
+        self._pgemm(ws, "gvoc", G0, ws["HsC"], self.gP["linear2vocab.weight"], scratch, self.vgd, a_kmajor=True, b_kmajor=True,
+                    shared=True, a_scale=colsc)
 
     def _order_tokens(self, ws, n, rows, main, side, after=None):
         """The rows of the token matrix listed by token (what the reproducible embedding gradients sum by): it
@@ -1305,6 +1324,11 @@ class A2CEngine:
                 hip.chain_pair_fwd_seg(*pair_args, **pair_opts)
         if "order_pending" in ws:
             self._order_tokens(ws, *ws.pop("order_pending"), main, side, after=ev_tok)
+            if self.vgd == "f16x2" and self.concurrent:
+                # G0's scales (a pass over the [rows, V] matrix for the per-word ones): beside the forward chains
+                with torch.cuda.stream(self._check_stream()):
+                    self._check_stream().wait_event(ev_tok)
+                    self._g0_scales(ws, ws["dlogits"].view(s * n, self.vocab), True)
         if pair and backward:
             # the value network's embedding rows, which only its input-side weight gradient reads: gathered
             # beside the chains instead of at the end of the step (the side stream's later events cover it)
@@ -1342,7 +1366,9 @@ class A2CEngine:
                 hip.chain_pair_replay_check(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["XPr"],
                                             R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], ws["saved_r"],
                                             n, p0, p0 + 1, s, fc, replay_steps, ws["work_cv"], ws["work_cr"],
-                                            ws["ctl"][6:8])
+                                            ws["ctl"][6:8],
+                                            arith="f16x2" if (self.chain_arith == "f16x2" and self.persistent
+                                                              and hip.chain_f16x2_supported(s - fc)) else "f32")
                 ws["replay_host"].copy_(ws["ctl"][6:8], non_blocking=True)
                 ev_replay = torch.cuda.Event()
                 ev_replay.record(check)
@@ -1413,6 +1439,49 @@ class A2CEngine:
         if weights:
             self._value_head_weight_grads(ws, features, n, s, ws["scratch_main"], ws["cs_main"])
 
+    def _scale_of(self, ws, key, x, cols):
+        """Power-of-two scales for a two-piece f16 product (hipabi.gemm, dtype "f16x2"): one per row of x, or with
+        `cols` one per column, from one pass over x on the current stream.  Kept in ws under `key` (one per call site:
+        products on different streams must not share them)."""
+        r, c = x.shape
+        count = c if cols else r
+        buf = ws.get("sc16_" + key)
+        if buf is None or buf[0].numel() < count or buf[1].numel() < r + c:
+            buf = ws["sc16_" + key] = (torch.empty(count, dtype=torch.float32, device=self.device),
+                                       torch.empty(r + c, dtype=torch.int32, device=self.device))
+        hip.absmax_scales(x, buf[1], col_scale=buf[0] if cols else None, row_scale=None if cols else buf[0])
+        return buf[0]
+
+    def _pgemm(self, ws, tag, a, b, out, scratch, dtype, a_kmajor=False, b_kmajor=False, shared=False, a_scale=None,
+               b_scale=None):
+        """A product of the backward pass in the arithmetic `dtype` (hipabi.gemm_auto).  With "f16x2" the operands'
+        scales are computed here, a pass over each, unless the caller hands them in (an operand of two products)."""
+        if dtype == "f16x2":
+            if a_scale is None:
+                a_scale = self._scale_of(ws, tag + "a", a, a_kmajor)
+            if b_scale is None:
+                b_scale = self._scale_of(ws, tag + "b", b, b_kmajor)
+        else:
+            a_scale = b_scale = None
+        hip.gemm_auto(a, b, out, scratch, a_kmajor=a_kmajor, b_kmajor=b_kmajor, shared=shared, dtype=dtype, a_scale=a_scale,
+                      b_scale=b_scale)
+
+    def _g0_scales(self, ws, G0, want_cols):
+        """Scales of G0 = onehot(token) - softmax for the two-piece products, on the current stream: per row from the
+        rows' log-probabilities (hipabi.g0_row_scales), per column (one pass over the matrix) when asked for.
+        Computed once per rollout; returns (row scales, column scales or None, event after which they are complete)."""
+        got = ws.get("g0_scales")
+        if got is None or got[0] != ws["rollout_id"] or (want_cols and got[2] is None):
+            rows = ws.get("g0_row_scale")
+            if rows is None or rows.numel() < G0.shape[0]:
+                rows = ws["g0_row_scale"] = torch.empty(G0.shape[0], dtype=torch.float32, device=self.device)
+            hip.g0_row_scales(ws["logp"].view(-1)[:G0.shape[0]], rows)
+            colsc = self._scale_of(ws, "g0c", G0, True) if want_cols else None
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            got = ws["g0_scales"] = (ws["rollout_id"], rows, colsc, ev)
+        return got[1], got[2], got[3]
+
     def _value_head_weight_grads(self, ws, features, n, s, scratch, cs):
         """Weight and bias gradients of the value head's two linear layers, from ws["dvalue"] and ws["dY"], on the
         current stream; scratch / cs: split-K slabs and fixed-order column-sum partials of that stream."""
@@ -1423,7 +1492,7 @@ class A2CEngine:
         hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], scratch, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
         hip.colsum(dvalue, gV["linear2.bias"], scratch=cs)
         gw1 = gV["linear1.weight"]
-        hip.gemm_auto(dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, a_kmajor=True, b_kmajor=True, dtype=self.gd)
+        self._pgemm(ws, "gw1h", dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, self.gd, a_kmajor=True, b_kmajor=True)
         gw1[:, self.F:].copy_(ws["gw1h"])
         hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1), scratch=cs)
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
@@ -1469,7 +1538,9 @@ class A2CEngine:
             # per CU) in front of it the chain's persistent launch (84 KB per workgroup) found no CU to start on for
             # 0.9 ms (kernel trace: BPTT from 4.43 ms into the step, against 3.60 ms in this order)
             ev_dhall, ev_vocab = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
-            # the policy LSTM's backward-through-time: one persistent launch, right behind the value chain's
+
+        def policy_bptt():
+            # the policy LSTM's backward-through-time: one persistent launch
             main.wait_event(ev_dhall)
             arith = "f16x2" if self._bwd_f16x2(n) else "f32"
             if "work_p" not in ws:
@@ -1478,8 +1549,13 @@ class A2CEngine:
             hip.policy_lstm_bptt_persist(ws["gates"], ws["Cbuf"], ws["dHall"], self.P["lstm.weight_hh_l0"], ws["dgp"],
                                          ws["dh0"], ws["work_p"], ws["status"][3:4], arith=arith)
             self._mark("policy_bptt_done")
-            ev_pbptt = torch.cuda.Event()
-            ev_pbptt.record(main)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            return ev
+        if tail:
+            # right behind the value chain's launch (measured: behind the value network's weight gradients instead,
+            # 5.70 against 5.45 ms a minibatch)
+            ev_pbptt = policy_bptt()
         if plan[0] == "segmented":
             # every word the host reads back (backward seam error, the chain kernels' status words) is final here
             ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
@@ -1512,8 +1588,8 @@ class A2CEngine:
         back = n if plan[0] == "rows" else 1
         if tv > back:
             h_prev = saved.view(tv, 6 * H)[:tv - back, 5 * H:]
-            hip.gemm_auto(dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], sm, a_kmajor=True, b_kmajor=True,
-                          dtype=self.gd)
+            self._pgemm(ws, "vhh", dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], sm, self.gd, a_kmajor=True,
+                        b_kmajor=True)
         else:
             gV["valrnn.lstm.weight_hh_l0"].zero_()
         self._mark("value_wgrads_done")
@@ -1527,14 +1603,15 @@ class A2CEngine:
         if ev_loss is not None and not ws.pop("Xv_gathered", False):
             # the A2C step took its input projections from the per-word table: gather x now
             hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
-        hip.gemm_auto(dgsum, ws["Xv"], gV["valrnn.lstm.weight_ih_l0"], sm, a_kmajor=True, b_kmajor=True, dtype=self.gd)
+        self._pgemm(ws, "vih", dgsum[:lv * n], ws["Xv"][:lv * n], gV["valrnn.lstm.weight_ih_l0"], sm, self.gd, a_kmajor=True,
+                    b_kmajor=True)
         hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_main"])
         gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
         g_emb = gV.get("valrnn.caption_embedding.weight")
         if g_emb is not None:
             if ws.get("ev_order_done") is not None:
                 main.wait_event(ws["ev_order_done"])
-            hip.gemm_auto(dgsum, V["valrnn.lstm.weight_ih_l0"], ws["dXv"], sm, b_kmajor=True, dtype=self.gd)
+            self._pgemm(ws, "vdx", dgsum[:lv * n], V["valrnn.lstm.weight_ih_l0"], ws["dXv"][:lv * n], sm, self.gd, b_kmajor=True)
             hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
         self._mark("value_input_grads_done")
         if tail:
@@ -1569,7 +1646,7 @@ class A2CEngine:
         if ws.get("policy_early"):
             cur.wait_event(ws["ev_early"])
         else:
-            hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ss, b_kmajor=True, shared=True, dtype=self.vgd)
+            self._uvocab(ws, G0, ss)
         dHall = ws["dHall"]
         if p0 > 1:
             dHall[:p0 - 1].zero_()
@@ -1582,8 +1659,7 @@ class A2CEngine:
         with torch.cuda.stream(other):
             other.wait_event(ev_scaled)
             sc, cs = (ws["scratch_check"], ws["cs_check"]) if other is not cur else (ss, ws["cs_side"])
-            hip.gemm_auto(G0, ws["HsC"], gP["linear2vocab.weight"], sc, a_kmajor=True, b_kmajor=True, shared=True,
-                          dtype=self.vgd)
+            self._vocab_weight_grad(ws, G0, sc)
             hip.colsum(G0, gP["linear2vocab.bias"], scratch=cs, row_scale=coef)
             ev_vocab = torch.cuda.Event()
             ev_vocab.record(other)
@@ -1613,15 +1689,16 @@ class A2CEngine:
             ws["X_pending"] = False
         dgp = ws["dgp"]
         dg_all = dgp.view(t_steps * n, 4 * H)
-        hip.gemm_auto(dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, a_kmajor=True, b_kmajor=True,
-                      shared=True, dtype=self.vgd)
-        hip.gemm_auto(dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, a_kmajor=True,
-                      b_kmajor=True, shared=True, dtype=self.vgd)
+        dg_cols = self._scale_of(ws, "pdgc", dg_all, True) if self.vgd == "f16x2" else None
+        self._pgemm(ws, "pih", dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, self.vgd, a_kmajor=True,
+                    b_kmajor=True, shared=True, a_scale=dg_cols)
+        self._pgemm(ws, "phh", dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, self.vgd,
+                    a_kmajor=True, b_kmajor=True, shared=True, a_scale=dg_cols)
         hip.colsum(dg_all, gP["lstm.bias_ih_l0"], scratch=ws["cs_side"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
-            hip.gemm_auto(dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, b_kmajor=True, shared=True, dtype=self.vgd)
+            self._pgemm(ws, "pdx", dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, self.vgd, b_kmajor=True, shared=True)
             hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
         hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])
@@ -1642,8 +1719,7 @@ class A2CEngine:
             if ws.get("policy_early"):
                 check.wait_event(ws["ev_early"])
             else:
-                hip.gemm_auto(G0, P["linear2vocab.weight"], ws["Uvocab"], ws["scratch_check"], b_kmajor=True, shared=True,
-                              dtype=self.vgd)
+                self._uvocab(ws, G0, ws["scratch_check"])
                 ws["policy_early"], ws["ev_early"] = True, torch.cuda.Event()
                 ws["ev_early"].record(check)
             dHall = ws["dHall"]
@@ -1653,6 +1729,15 @@ class A2CEngine:
             ev_dhall = torch.cuda.Event()
             ev_dhall.record(check)
             self._mark("check:policy_dH_done")
+            # the vocabulary matrix's gradients follow on the same stream, beside the value chain's BPTT (whose
+            # workgroups hold half of the CUs); on the side stream they queued behind the replay check and ran after
+            # both BPTT launches, when nothing was left to run beside them
+            hip.scale_rows(Hs, coef, ws["HsC"])
+            self._vocab_weight_grad(ws, G0, ws["scratch_check"])
+            hip.colsum(G0, gP["linear2vocab.bias"], scratch=ws["cs_check"], row_scale=coef)
+            ev_vocab = torch.cuda.Event()
+            ev_vocab.record(check)
+            self._mark("check:vocab_grads_done")
             pending = ws.pop("head_grads_pending", None)
             if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
                 self._value_head_weight_grads(ws, *pending, ws["scratch_check"], ws["cs_check"])
@@ -1668,11 +1753,4 @@ class A2CEngine:
                 hip.gather_rows(P["caption_embedding.weight"], ws["tokT"].view(-1), 1, t_steps * n,
                                 ws["X"].view(t_steps * n, -1))
                 ws["X_pending"] = False
-            hip.scale_rows(Hs, coef, ws["HsC"])
-            hip.gemm_auto(G0, ws["HsC"], gP["linear2vocab.weight"], ws["scratch_side"], a_kmajor=True, b_kmajor=True,
-                          shared=True, dtype=self.vgd)
-            hip.colsum(G0, gP["linear2vocab.bias"], scratch=ws["cs_side"], row_scale=coef)
-            ev_vocab = torch.cuda.Event()
-            ev_vocab.record(side)
-            self._mark("side:vocab_grads_done")
         return ev_dhall, ev_vocab

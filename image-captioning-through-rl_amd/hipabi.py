@@ -34,6 +34,12 @@ SIGNATURES = {
     "icrl_f16x2_piece_halves": (c_i64, [c_int, c_int]),
     "icrl_cut_f16x2": (c_int, [c_vp, c_i64, c_int, c_int, ctypes.c_float, c_vp, c_vp, c_vp]),
     "icrl_gemm_f16x2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
+    "icrl_gemm_f16x2s": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int,
+                                 c_vp, c_int, c_vp]),
+    "icrl_gemm_f16x2s_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_int,
+                                        c_int, c_int, c_vp]),
+    "icrl_absmax_scales": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "icrl_g0_row_scales": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
     "icrl_chain_seg_workspace_floats": (c_i64, [c_int]),
     "icrl_lstm_chain_fwd_seg": (c_int, [c_vp, c_vp] + [c_int] * 6 + [c_vp] * 6),
@@ -53,6 +59,7 @@ SIGNATURES = {
     "icrl_chain_bwd_warm16_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_warm16": (c_int, [c_vp] * 3 + [c_int] * 7 + [c_vp] * 4),
     "icrl_chain_pair_replay_check": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
+    "icrl_chain_pair_replay_check_f16x2": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
     "icrl_lstm_chain_bwd_rows": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_gru_chain_fwd_seg": (c_int, [c_vp] * 3 + [c_int] * 6 + [c_vp] * 5),
@@ -234,12 +241,13 @@ def _f32c(t):
 
 
 def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, bias2=None, accumulate=False,
-         m=None, n=None, k=None, lda=None, ldb=None, ldc=None, tile=0, dtype="f32"):
+         m=None, n=None, k=None, lda=None, ldb=None, ldc=None, tile=0, dtype="f32", a_scale=None, b_scale=None):
     """out[M,N] (+)= A[M,K] @ B[K,N] (+ bias + bias2).  tile: 0 = by shape, 1 = 128x128, 2 = 128x64, 3 = 64x64.
     dtype "bf16": operands rounded to bf16 on chip, products on the bf16 matrix instruction, float32 sums
     (tiles 1 and 3 only).  dtype "f32x3": every element cut into three bf16 pieces on chip, six piece products per
     element product on the bf16 matrix instruction: f32 rounding-level accuracy at about twice the f32 kernel's rate
-    on long products (128x128 tiles only; no a_rows, no bias2).
+    on long products (128x128 tiles only; no a_rows, no bias2).  dtype "f16x2": the same with two f16 pieces of the
+    elements scaled by a_scale[row of A] / b_scale[row of B] (powers of two from absmax_scales), three piece products.
 
     a: stored [M, K] (a_kmajor False) or [K, M] (True); b: stored [N, K] (False, an
     nn.Linear weight) or [K, N] (True).  2-D tensors whose last dimension is contiguous;
@@ -259,7 +267,17 @@ def gemm(a, b, out, *, a_kmajor=False, b_kmajor=False, a_rows=None, bias=None, b
     ldc = out.stride(0) if ldc is None else ldc
     if a_rows is not None:
         assert a_rows.dtype == torch.int64 and a_rows.is_contiguous()
-    assert dtype in ("f32", "bf16", "f32x3")
+    assert dtype in ("f32", "bf16", "f32x3", "f16x2")
+    if dtype == "f16x2":
+        # two scaled f16 pieces per element, three piece products: a_scale [m] / b_scale [n] from absmax_scales
+        assert a_rows is None and bias2 is None
+        for t, count in ((a_scale, m), (b_scale, n)):
+            assert t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= count
+        with _Timed("gemm_f16x2s", 2.0 * m * n * k, 4.0 * (m * k + k * n + m * n)):
+            rc = load().icrl_gemm_f16x2s(_ptr(a), lda, int(a_kmajor), _ptr(a_scale), _ptr(b), ldb, int(b_kmajor), _ptr(b_scale),
+                                         _ptr(out), ldc, m, n, k, _ptr(bias), int(accumulate), _stream())
+        _check(rc, "icrl_gemm_f16x2s")
+        return out
     if dtype == "bf16":
         fn, kind, tile = load().icrl_gemm_bf16, "gemm_bf16", (1 if tile == 2 else tile)
     elif dtype == "f32x3":
@@ -552,12 +570,20 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
            "icrl_adam_step")
 
 
-def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0, dtype="f32"):
+def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0, dtype="f32", a_scale=None, b_scale=None):
     """slabs[z] = partial product of split z; slabs is [splits, M, N] contiguous."""
     m = a.shape[1] if a_kmajor else a.shape[0]
     k = a.shape[0] if a_kmajor else a.shape[1]
     n = b.shape[1] if b_kmajor else b.shape[0]
     assert slabs.shape == (splits, m, n) and slabs.is_contiguous()
+    if dtype == "f16x2":
+        for t, count in ((a_scale, m), (b_scale, n)):
+            assert t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= count
+        with _Timed("gemm_f16x2s", 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
+            rc = load().icrl_gemm_f16x2s_splitk(_ptr(a), a.stride(0), int(a_kmajor), _ptr(a_scale), _ptr(b), b.stride(0),
+                                                int(b_kmajor), _ptr(b_scale), _ptr(slabs), n, m * n, m, n, k, splits, _stream())
+        _check(rc, "icrl_gemm_f16x2s_splitk")
+        return
     if dtype == "bf16":
         fn, kind, tile = load().icrl_gemm_bf16_splitk, "gemm_bf16", (1 if tile == 2 else tile)
     elif dtype == "f32x3":
@@ -626,7 +652,7 @@ def _plan_gemm(m, n, k, out_contiguous=True, shared=False):
 
 
 def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None, shared=False,
-              dtype="f32"):
+              dtype="f32", a_scale=None, b_scale=None):
     """gemm() with the tile / split-K choice of plan_gemm(); `scratch` is a flat float32 buffer for
     the split-K partial slabs (summed in a fixed order, so results are reproducible)."""
     m = a.shape[1] if a_kmajor else a.shape[0]
@@ -638,7 +664,7 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         # the bf16 kernel's plans, from its own sweep: long k over large outputs in 128x128 tiles with k in four,
         # long k over small outputs in 64x64 tiles with k in two, k ~ 2000 unsplit in 64x64 tiles
         tile, splits = ((1, 4) if m * n >= (1 << 21) else (3, 2)) if k >= 4096 else (3, 1)
-    if dtype == "f32x3":
+    if dtype in ("f32x3", "f16x2"):
         # 128x128 tiles, 36 KB of LDS each: two workgroups fit a CU beside a persistent chain workgroup and the kernel
         # runs as fast at two or three per CU as at four, so the split is the one whose workgroups fill whole turns
         # of 512 places best (measured: k in five for 304 tiles, in eight for 316 and for 64)
@@ -649,10 +675,29 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:
         slabs = scratch[:splits * m * n].view(splits, m, n)
-        gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor, tile=tile, dtype=dtype)
+        gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor, tile=tile, dtype=dtype, a_scale=a_scale,
+                    b_scale=b_scale)
         sum_slabs(slabs, out, accumulate=accumulate)
         return out
-    return gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias, tile=tile, dtype=dtype)
+    return gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor, accumulate=accumulate, bias=bias, tile=tile, dtype=dtype,
+                a_scale=a_scale, b_scale=b_scale)
+
+
+def absmax_scales(x, work, row_scale=None, col_scale=None):
+    """Power-of-two scales for gemm(dtype="f16x2"): row_scale[r] / col_scale[c] brings the largest magnitude of row r /
+    column c of x [rows, cols] (float32, last dimension contiguous) into [2^14, 2^15).  work: int32, rows + cols."""
+    rows, cols = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and work.dtype == torch.int32 and work.numel() >= rows + cols
+    for t, count in ((row_scale, rows), (col_scale, cols)):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= count)
+    _check(load().icrl_absmax_scales(_ptr(x), x.stride(0), rows, cols, _ptr(row_scale), _ptr(col_scale), _ptr(work), _stream()),
+           "icrl_absmax_scales")
+
+
+def g0_row_scales(log_prob, scale):
+    """Scales of the rows of G0 = onehot(token) - softmax (largest magnitude 1 - p_token) from their log-probabilities."""
+    assert log_prob.dtype == scale.dtype == torch.float32 and log_prob.is_contiguous() and scale.numel() >= log_prob.numel()
+    _check(load().icrl_g0_row_scales(_ptr(log_prob), log_prob.numel(), _ptr(scale), _stream()), "icrl_g0_row_scales")
 
 
 def chain_seg_workspace_floats(segments):
@@ -762,7 +807,7 @@ def chain_pair_fwd_seg(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, 
 
 
 def chain_pair_replay_check(xproj_v, w_hh_v, saved_v, xproj_r, w_hh_r, b_hh_r, saved_r, n, p0_v, p0_r, n_calls, full_calls,
-                            steps, work_v, work_r, err):
+                            steps, work_v, work_r, err, arith="f32"):
     """Runs, for every call whose replay the chains left out (full_calls < n_calls), the first `steps` positions
     of that replay from the state the chain had before the call, and writes to err[0:2] how far the value LSTM's /
     reward GRU's state then is from the state the last fully walked call had there."""
@@ -773,8 +818,10 @@ def chain_pair_replay_check(xproj_v, w_hh_v, saved_v, xproj_r, w_hh_r, b_hh_r, s
     assert xproj_v.numel() >= steps * 4 * 512 and xproj_r.numel() >= steps * 3 * 512
     assert work_v.numel() >= chain_seg_workspace_floats(rows) and work_r.numel() >= chain_seg_workspace_floats(rows)
     assert err.numel() >= 2
+    assert arith in ("f32", "f16x2")
+    fn = load().icrl_chain_pair_replay_check_f16x2 if arith == "f16x2" else load().icrl_chain_pair_replay_check
     with _Timed("replay_check", rows * steps, steps=steps + 1):
-        rc = load().icrl_chain_pair_replay_check(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(saved_v)),
+        rc = fn(_ptr(_f32c(xproj_v)), _ptr(_f32c(w_hh_v)), _ptr(_f32c(saved_v)),
                                                  _ptr(_f32c(xproj_r)), _ptr(_f32c(w_hh_r)), _ptr(_f32c(b_hh_r)),
                                                  _ptr(_f32c(saved_r)), n, p0_v, p0_r, n_calls, full_calls, steps,
                                                  _ptr(_f32c(work_v)), _ptr(_f32c(work_r)), _ptr(_f32c(err)), _stream())

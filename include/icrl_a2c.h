@@ -110,6 +110,28 @@ int icrl_cut_f16x2(const float* x, int64_t ld, int rows, int K, float fixed_scal
 int icrl_gemm_f16x2(const void* a_pieces, const float* a_descale, const void* b_pieces, const float* b_descale,
                     float* C, int64_t ldc, int M, int N, int K, const float* bias, icrl_stream_t stream);
 
+/* icrl_gemm_f32x3's products once more on two f16 pieces per element: the caller supplies a power-of-two scale for
+ * every row of A and of B as the product sees them (a_scale[M], b_scale[N]: constant along k), which brings the row's
+ * largest magnitude into [2^14, 2^15); an element is cut on chip into hi + mid of its scaled value (2^-22 relative
+ * wherever both are normal f16 numbers), a product is hi.hi + hi.mid + mid.hi on v_mfma_f32_32x32x16_f16 with float32
+ * sums, and the epilogue divides the scales out (exactly).  Half the matrix instructions and two thirds of the LDS
+ * traffic of the three-piece kernel, 1.45-1.6 times its rate on the backward pass's shapes; accuracy of the same
+ * class (2^-21 per element product).  Same layouts, tiles and split-K slabs as icrl_gemm_f32x3; no row gather, one
+ * bias.  For the same products (autograd of models.py:80-82, 133 at trainers.py:479).
+ * icrl_absmax_scales computes such scales for x [rows, cols] (row stride ld): row_scale[rows] and / or
+ * col_scale[cols] (either may be null); `work` holds rows + cols 32-bit words.  icrl_g0_row_scales gives them for the
+ * rows of G0 = onehot(token) - softmax from the rows' log-probabilities alone (the largest magnitude of such a row is
+ * 1 - p_token). */
+int icrl_gemm_f16x2s(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B, int64_t ldb,
+                     int b_kmajor, const float* b_scale, float* C, int64_t ldc, int M, int N, int K,
+                     const float* bias, int accumulate, icrl_stream_t stream);
+int icrl_gemm_f16x2s_splitk(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B,
+                            int64_t ldb, int b_kmajor, const float* b_scale, float* C_slabs, int64_t ldc,
+                            int64_t slab_stride, int M, int N, int K, int splits, icrl_stream_t stream);
+int icrl_absmax_scales(const float* x, int64_t ld, int rows, int cols, float* row_scale, float* col_scale,
+                       unsigned* work, icrl_stream_t stream);
+int icrl_g0_row_scales(const float* log_prob, int count, float* scale, icrl_stream_t stream);
+
 /* out[i] = (accumulate ? out[i] : 0) + sum_z slabs[z*slab_stride + i], i < count (count % 4 == 0) */
 int icrl_sum_slabs(const float* slabs, int64_t slab_stride, int splits, int64_t count, float* out,
                    int accumulate, icrl_stream_t stream);
@@ -448,6 +470,12 @@ int icrl_chain_pair_replay_check(const float* xproj_v, const float* w_hh_v, cons
                                  const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
                                  const float* saved_r, int N, int p0_v, int p0_r, int n_calls, int full_calls,
                                  int steps, float* work_v, float* work_r, float* err, icrl_stream_t stream);
+/* The same check with the replays walked by the f16 launch of icrl_chain_pair_fwd_seg_f16x2 (two scaled f16 pieces
+ * per operand, float32-level accuracy; about half the time per step): for chains that were walked with it. */
+int icrl_chain_pair_replay_check_f16x2(const float* xproj_v, const float* w_hh_v, const float* saved_v,
+                                       const float* xproj_r, const float* w_hh_r, const float* b_hh_r,
+                                       const float* saved_r, int N, int p0_v, int p0_r, int n_calls, int full_calls,
+                                       int steps, float* work_v, float* work_r, float* err, icrl_stream_t stream);
 
 /* One forward chain alone in the same persistent launch (the look-ahead decoder's value calls,
  * trainers.py:73-105, and the pre-training loops, trainers.py:125-199, run one chain at a time):

@@ -104,8 +104,9 @@ def test_chains_with_replays_left_out_match_their_float64_restatement(n, p0, cal
         assert torch.equal(g2, g) and torch.equal(saved_r2, saved_r)
 
 
+@pytest.mark.parametrize("arith", ["f32", "f16x2"])
 @pytest.mark.parametrize("forget_shift", [0.0, 5.0])
-def test_replay_check_measures_what_the_exact_kernels_compute(forget_shift):
+def test_replay_check_measures_what_the_exact_kernels_compute(forget_shift, arith):
     """fc = 2 of 6 calls left in full: for calls 2..5 the check replays the first `steps` inputs from the state the
     chain had before the call.  The same replays, one at a time, on the exact chain kernels give the error it
     must report; with a long memory (forget / update gates near 1) that error is far from rounding."""
@@ -125,7 +126,8 @@ def test_replay_check_measures_what_the_exact_kernels_compute(forget_shift):
     rows = calls - fc
     cw_v, cw_r = (torch.zeros(hip.chain_seg_workspace_floats(rows), device="cuda") for _ in range(2))
     err = torch.full((2,), 7.0, device="cuda")
-    hip.chain_pair_replay_check(xv, wv, saved_v, xr, wr, br, saved_r, n, p0, p0 + 1, calls, fc, steps, cw_v, cw_r, err)
+    hip.chain_pair_replay_check(xv, wv, saved_v, xr, wr, br, saved_r, n, p0, p0 + 1, calls, fc, steps, cw_v, cw_r, err,
+                                arith=arith)
     torch.cuda.synchronize()
     # the same on the exact kernels: chain of `steps` positions (one call of one column of `steps` rows) from state_in
     sync, status = torch.zeros(hip.chain_sync_bytes(), dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -152,9 +154,11 @@ def test_replay_check_measures_what_the_exact_kernels_compute(forget_shift):
     got = err.cpu().tolist()
     if forget_shift:
         assert min(want) > 1e-3, "the long-memory chains were meant not to forget in %d steps" % steps
-        np.testing.assert_allclose(got, want, rtol=2e-3)
+        # (the f16 launch's products differ from the exact kernels' at float32 rounding level, and a long memory
+        # carries such differences along: the same error to a few per cent)
+        np.testing.assert_allclose(got, want, rtol=2e-3 if arith == "f32" else 5e-2)
     else:
-        assert max(want) < 2e-6 and max(got) < 2e-6, (got, want)
+        assert max(want) < 2e-6 and max(got) < (2e-6 if arith == "f32" else 4e-6), (got, want)
 
 
 # --------------------------------------------------------------------------- whole minibatches

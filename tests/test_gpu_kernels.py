@@ -752,6 +752,88 @@ def test_f16x2_gemm_rejects_what_it_does_not_do():
     assert rc != 0 and b"ldc" in hip.load().icrl_last_error()
 
 
+# --------------------------------------------------------------------------- scaled two-piece f16 products
+def _scales_for(x_rows):
+    """Reference for absmax_scales along the last axis: 2^(15 - e) with max|row| = f 2^e, f in [0.5, 1)."""
+    top = np.abs(x_rows).max(axis=1)
+    _, e = np.frexp(top)
+    return np.where(top > 0, np.ldexp(1.0, 15 - e), 2.0 ** 15).astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 256), (9728, 2048), (70, 1000), (300, 12)])
+def test_absmax_scales_rows_and_columns(rows, cols):
+    rs = np.random.RandomState(rows + cols)
+    x = rnd(rs, rows, cols + 4) * np.exp(rs.standard_normal((rows, 1)) * 4).astype(np.float32)
+    x[:, 8] *= 1e-6
+    x[min(3, rows - 1)] = 0.
+    xd = dev(x)[:, :cols]
+    work = torch.zeros(rows + cols, dtype=torch.int32, device="cuda")
+    rscale, cscale = torch.zeros(rows, device="cuda"), torch.zeros(cols, device="cuda")
+    hip.absmax_scales(xd, work, row_scale=rscale, col_scale=cscale)
+    np.testing.assert_array_equal(rscale.cpu().numpy(), _scales_for(x[:, :cols]))
+    np.testing.assert_array_equal(cscale.cpu().numpy(), _scales_for(x[:, :cols].T))
+    only_c = torch.zeros(cols, device="cuda")
+    hip.absmax_scales(xd, work, col_scale=only_c)
+    assert torch.equal(only_c, cscale)
+    scaled = np.abs(x[:, :cols]).max(axis=1) * rscale.cpu().numpy()
+    assert ((scaled[scaled > 0] >= 2 ** 14) & (scaled[scaled > 0] < 2 ** 15)).all()
+
+
+def test_g0_row_scales_bound_the_row():
+    """The scale computed from log p_token keeps every entry of onehot - softmax below f16's largest number and the
+    token entry at 2^13 or above (the estimate may sit one binade off the exact row maximum, never more)."""
+    rs = np.random.RandomState(3)
+    logits = rnd(rs, 400, 1000) * np.linspace(0.1, 30, 400, dtype=np.float32)[:, None]
+    p = torch.softmax(torch.from_numpy(logits).double(), 1)
+    tok = torch.from_numpy(rs.randint(0, 1000, size=400))
+    tok[:200] = p[:200].argmax(1)
+    g0 = -p.clone()
+    g0[torch.arange(400), tok] += 1.0
+    logp = torch.log(p[torch.arange(400), tok]).float().cuda()
+    scale = torch.zeros(400, device="cuda")
+    hip.g0_row_scales(logp, scale)
+    scaled = (g0.abs().max(1).values * scale.cpu().double()).numpy()
+    assert (scaled < 65504).all()
+    exact = g0.abs().max(1).values.numpy() > 2.0 ** -21
+    assert (scaled[exact] >= 2 ** 13).all()
+
+
+@pytest.mark.parametrize("a_km", [False, True])
+@pytest.mark.parametrize("b_km", [False, True])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 130, 333), (77, 300, 2050), (2048, 512, 9728)])
+def test_f16x2s_gemm_layouts(a_km, b_km, shape):
+    """icrl_gemm_f16x2s with the scales icrl_absmax_scales makes, every layout, split-K included, against float64;
+    rows of both operands span many orders of magnitude (what the scales are for).  Error bound of an f32 product
+    with room for the pieces' 2^-21."""
+    m, n, k = shape
+    rs = np.random.RandomState(m + n + k)
+    a = rnd(rs, m, k) * np.exp(rs.standard_normal((m, 1)) * 4).astype(np.float32)
+    b = rnd(rs, n, k) * np.exp(rs.standard_normal((n, 1)) * 4).astype(np.float32)
+    a[:, ::7] *= 1e-4
+    a_st, b_st = dev(a.T.copy() if a_km else a), dev(b.T.copy() if b_km else b)
+    work = torch.zeros(max(m, n) + k, dtype=torch.int32, device="cuda")
+    sa, sb = torch.zeros(m, device="cuda"), torch.zeros(n, device="cuda")
+    hip.absmax_scales(a_st, work, **({"col_scale": sa} if a_km else {"row_scale": sa}))
+    hip.absmax_scales(b_st, work, **({"col_scale": sb} if b_km else {"row_scale": sb}))
+    bias = dev(rnd(rs, n))
+    out = torch.empty(m, n, device="cuda")
+    hip.gemm(a_st, b_st, out, a_kmajor=a_km, b_kmajor=b_km, bias=bias, dtype="f16x2", a_scale=sa, b_scale=sb)
+    want = a.astype(np.float64) @ b.astype(np.float64).T
+    bound = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T
+    err = np.abs(out.cpu().numpy().astype(np.float64) - bias.cpu().numpy() - want) / (bound + np.abs(bias.cpu().numpy()))
+    print("%s km %d%d: max |error| / sum|a||b| = %.3g" % (shape, a_km, b_km, err.max()))
+    assert err.max() < 1e-6
+    scratch = torch.empty(8 * m * n, device="cuda")
+    auto = torch.empty(m, n, device="cuda")
+    hip.gemm_auto(a_st, b_st, auto, scratch, a_kmajor=a_km, b_kmajor=b_km, shared=True, dtype="f16x2", a_scale=sa, b_scale=sb)
+    err = np.abs(auto.cpu().numpy().astype(np.float64) - want) / bound
+    assert err.max() < 1e-6
+    acc = out.clone()
+    hip.gemm(a_st, b_st, acc, a_kmajor=a_km, b_kmajor=b_km, accumulate=True, dtype="f16x2", a_scale=sa, b_scale=sb)
+    twice = np.abs(acc.cpu().numpy().astype(np.float64) - bias.cpu().numpy() - 2 * want) / (bound + np.abs(bias.cpu().numpy()))
+    assert twice.max() < 2e-6
+
+
 # --------------------------------------------------------------------------- policy LSTM backward-through-time
 @pytest.mark.parametrize("n,t_steps,dtype", [(512, 19, "f32"), (48, 5, "f32"), (64, 3, "bf16")])
 def test_policy_lstm_bptt_equals_the_launches_issued_one_by_one_and_autograd(n, t_steps, dtype):
