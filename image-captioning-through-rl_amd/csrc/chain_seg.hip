@@ -350,6 +350,21 @@ __global__ __launch_bounds__(256) void seam_check_fwd(const float* __restrict__ 
     }
 }
 
+// What a persistent launch leaves behind when one of its waits runs out (give_up, below): abort word, then the
+// workgroup that gave up, the step it was at and a bit mask of the producers of its row group that had not reached
+// that step.  One line on stdout per such launch (device printf from the one-thread / first-thread kernels that run
+// behind every persistent launch, not from the chain kernels, whose register budgets it would cost).
+__device__ void report_abort(const unsigned* abort_w, int kind) {
+    if (*abort_w == 0) return;
+    static const char* const names[] = {"forward chain pair", "value chain BPTT", "replay check", "forward chain",
+                                        "per-row chains", "policy LSTM BPTT"};
+    (void)names;
+    printf("[icrl] a persistent launch (kind %d: 0 forward pair, 1 value BPTT, 2 replay check, 3 one forward chain, "
+           "4 per-row chains, 5 policy BPTT) gave up: workgroup %u had waited 20 ms at step %u for workgroups of its "
+           "row group, mask %08x (bit i: producer i behind; all bits set at step 1 = they never started, i.e. other "
+           "work held the CUs the launch needs)\n", kind, abort_w[1], abort_w[2], abort_w[3]);
+}
+
 // Both forward chains' seam checks and the abort poison in ONE launch (three tiny launches in a row sit on the
 // step's critical path): blocks [0, nb) check the LSTM chain's seams, blocks [nb, 2 nb) the GRU chain's; a launch
 // that gave up waiting (abort word set) reports +inf for both.
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(256) void seam_check_fwd_pair(const float* __restri
     if (threadIdx.x == 0) {
         d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (*abort_w != 0) d = INFINITY;
+        if (blockIdx.x == 0) report_abort(abort_w, 0);
         if (d > 0.f) atomic_max_nonneg(err, d);
     }
 }
@@ -685,6 +701,7 @@ __global__ __launch_bounds__(256) void seam_check_bwd(const float* __restrict__ 
         d = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         r = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         if (abort_w != nullptr && *abort_w != 0) { d = INFINITY; r = fmaxf(r, 1.f); }
+        if (abort_w != nullptr && blockIdx.x == 0) report_abort(abort_w, 1);
         if (d > 0.f) atomic_max_nonneg(err_abs, d);
         if (r > 0.f) atomic_max_nonneg(ref_abs, r);
     }
@@ -735,6 +752,16 @@ __device__ __forceinline__ v4u as_u4(float4 v) { return __builtin_bit_cast(v4u, 
 constexpr unsigned EPOCH_MASK = 0x00ffffffu;
 __device__ __forceinline__ unsigned my_xcd() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u; }  // XCC_ID[3:0]
 
+// A wait that has run out: the first wave to get here raises the abort word (which releases every other waiter) and
+// leaves who it is, the step it waited at and which producers were behind (lag: ballot over the polling lanes).
+__device__ __forceinline__ void give_up(unsigned* abort_w, unsigned step, unsigned long long lag, int lane) {
+    if (lane == 0 && __hip_atomic_exchange((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        abort_w[1] = blockIdx.x;
+        abort_w[2] = step;
+        abort_w[3] = (unsigned)lag;
+    }
+}
+
 // wave 0: lanes 0..15 each poll one producer's flag, lane 16 polls the abort word.  Returns whether all
 // 16 producers of the row group run on XCD `xcd` (then their plain stores sit in this XCD's L2, where
 // an sc1 load finds them).
@@ -748,7 +775,7 @@ __device__ __forceinline__ bool wait_row_group(unsigned* flags16, unsigned epoch
         if (__any(ab != 0)) return false;
         if (__all((v & EPOCH_MASK) >= epoch)) return __all((v >> 24) == xcd);
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            give_up(abort_w, epoch, __ballot(lane < 16 && (v & EPOCH_MASK) < epoch), lane);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -1037,7 +1064,7 @@ __device__ __forceinline__ bool wait_row_group32(unsigned* flags32, unsigned epo
         if (__any(ab != 0)) return false;
         if (__all(v >= epoch)) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            give_up(abort_w, epoch, __ballot(lane < 32 && v < epoch), lane);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -1751,7 +1778,7 @@ __device__ __forceinline__ bool wait_row_group32_xcd(unsigned* flags32, unsigned
         if (__any(ab != 0)) return false;
         if (__all((v & EPOCH_MASK) >= epoch)) return __all((v >> 24) == xcd);
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_store((gu32*)abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            give_up(abort_w, epoch, __ballot(lane < 32 && (v & EPOCH_MASK) < epoch), lane);
             return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -2159,8 +2186,9 @@ __global__ __launch_bounds__(512, 1) void seg_bwd_rs(RsArgs a, unsigned* abort_w
 }
 
 // after the seam checks: a launch that gave up waiting must not pass them
-__global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* seam_r) {
+__global__ void poison_on_abort(const unsigned* abort_w, float* seam_v, float* seam_r, int kind) {
     if (*abort_w != 0) { *seam_v = INFINITY; *seam_r = INFINITY; }
+    report_abort(abort_w, kind);
 }
 int seam_blocks(int64_t elems) { return (int)std::min<int64_t>(128, (elems + 255) / 256); }
 
@@ -2177,8 +2205,9 @@ __global__ __launch_bounds__(256) void zero_regions(ZeroArgs z) {
 }
 
 // a launch that gave up waiting, reported through a status word (the per-row chains have no seam error)
-__global__ void flag_on_abort(const unsigned* abort_w, int* status) {
+__global__ void flag_on_abort(const unsigned* abort_w, int* status, int kind) {
     if (*abort_w != 0) *status = 1;
+    report_abort(abort_w, kind);
 }
 
 // Workspace layouts (floats, kh = K * 512), K segments:
@@ -2680,7 +2709,7 @@ extern "C" int icrl_lstm_chain_fwd_seg_persist(const float* xproj, const float* 
     if (int rc = solo_persist(a, 4, work, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(a.g.K * 2 * H)), dim3(256), 0, st, a.seam_a, a.seam_b, a.g,
                        2 * H, seam_err);
-    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err, seam_err);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err, seam_err, 3);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -2702,7 +2731,7 @@ extern "C" int icrl_gru_chain_fwd_seg_persist(const float* xproj, const float* w
     unsigned* abort_w = nullptr;
     if (int rc = solo_persist(a, 3, work, st, &abort_w)) return rc;
     hipLaunchKernelGGL(seam_check_fwd, dim3(seam_blocks(a.g.K * H)), dim3(256), 0, st, a.seam_a, a.seam_b, a.g, H, seam_err);
-    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err, seam_err);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, seam_err, seam_err, 3);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -2867,7 +2896,7 @@ int replay_check(const char* who, bool f16x2, const float* xproj_v, const float*
                        target_v, rows, err);
     hipLaunchKernelGGL(replay_compare, dim3(seam_blocks(rows * H)), dim3(256), 0, st, r.seam_b, saved_r, 5, 4, -1,
                        target_r, rows, err + 1);
-    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, err, err + 1);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_w, err, err + 1, 2);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -2919,7 +2948,7 @@ extern "C" int icrl_chain_pair_fwd_rows(const float* xproj_v, const float* w_hh_
         r.xproj = xproj_r; r.w_hh = w_hh_r; r.b_hh = b_hh_r; r.saved = nullptr; r.h_emit = h_emit_r;
         unsigned* abort_w = nullptr;
         if (int rc = pair_persist(v, r, work_v, work_r, st, &abort_w)) return rc;
-        hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+        hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status, 4);
     } else {
         if (int rc = fwd_steps_lstm(v.g, xproj_v, w_hh_v, h_emit_v, saved_v, work_v, nullptr, st)) return rc;
         if (int rc = fwd_steps_gru(r.g, xproj_r, w_hh_r, b_hh_r, h_emit_r, nullptr, work_r, st)) return rc;
@@ -2945,7 +2974,7 @@ extern "C" int icrl_lstm_chain_bwd_rows(const float* w_hh, const float* saved, c
         a.w_hh = w_hh; a.saved = saved; a.d_emit = d_emit; a.dgv = dgates;
         unsigned* abort_w = nullptr;
         if (int rc = bwd_persist(a, work, st, &abort_w)) return rc;
-        hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+        hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status, 4);
     } else {
         if (int rc = bwd_steps(a.g, w_hh, saved, d_emit, dgates, work, st)) return rc;
     }
@@ -2983,7 +3012,7 @@ extern "C" int icrl_policy_lstm_bptt_persist(const float* gates_act, const float
     ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
     unsigned* abort_w = nullptr;
     if (int rc = bwd_persist(a, work, st, &abort_w, 0, nullptr, dh0)) return rc;
-    hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+    hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status, 5);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }
@@ -3049,7 +3078,27 @@ extern "C" int icrl_policy_lstm_bptt_f16x2(const float* gates_act, const float* 
     ICRL_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
     unsigned* abort_w = nullptr;
     if (int rc = bwd_rs(a, work, st, &abort_w, nullptr, dh0)) return rc;
-    hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status);
+    hipLaunchKernelGGL(flag_on_abort, dim3(1), dim3(1), 0, st, abort_w, status, 5);
+    ICRL_LAUNCH_CHECK();
+    return ICRL_OK;
+}
+
+
+// ------------------------------------------------------------------ the give-up path, on its own (test hook)
+namespace {
+__global__ void wait_that_runs_out(unsigned* flags, unsigned* abort_w, unsigned epoch, int wide) {
+    const int lane = threadIdx.x & 63;
+    if (wide) wait_row_group32(flags, epoch, abort_w, lane);
+    else wait_row_group(flags, epoch, abort_w, lane);
+}
+}  // namespace
+
+extern "C" int icrl_chain_give_up_selftest(unsigned* flags, unsigned* abort_words, unsigned epoch, int wide, float* err,
+                                           icrl_stream_t stream) {
+    ICRL_REQUIRE(flags && abort_words && err, "icrl_chain_give_up_selftest: null pointer");
+    hipStream_t st = icrl::as_stream(stream);
+    hipLaunchKernelGGL(wait_that_runs_out, dim3(1), dim3(64), 0, st, flags, abort_words, epoch, wide);
+    hipLaunchKernelGGL(poison_on_abort, dim3(1), dim3(1), 0, st, abort_words, err, err + 1, wide ? 0 : 1);
     ICRL_LAUNCH_CHECK();
     return ICRL_OK;
 }

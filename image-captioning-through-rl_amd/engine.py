@@ -1050,12 +1050,18 @@ class A2CEngine:
                 ok_v, ok_r = (all(e <= t for e, t in c) for c in (checks_v, checks_r))
                 if not (ok_v and ok_r):
                     self.fallbacks += 1
-                    if gave_up == 0 and any(e == float("inf") for e, _ in checks_v + checks_r):
+                    if any(e == float("inf") for e, _ in checks_v + checks_r):
                         # +inf is what a launch reports whose workgroups were not all resident in time (other
-                        # kernels held the CUs): that says nothing about the warm-up, so the same plans run once more
+                        # kernels held the CUs; the library prints who waited for whom): that says nothing about the
+                        # warm-up, so the same plans run again - and after MAX_GIVE_UPS such attempts with one
+                        # launch per step, which needs no workgroup to wait for another, instead of climbing the
+                        # warm-up ladder to the exact kernels on a signal that is not about warm-ups
                         gave_up += 1
                         self.launch_timeouts += 1
-                        continue
+                        if gave_up == self.MAX_GIVE_UPS:
+                            self._degrade_to_per_step_launches()
+                        if gave_up <= self.MAX_GIVE_UPS:
+                            continue
                     if (self._warm16_active(pv, pr) and not (self._ladder_fv.probing or self._ladder_fr.probing)
                             and self._sudden(self._ladder_fv, fv, ok_v) and self._sudden(self._ladder_fr, fr, ok_r)):
                         # the 16-bit part of the warm-up may be what failed (not so when a shorter warm-up was being
@@ -1105,6 +1111,16 @@ class A2CEngine:
                     self._ladder_bwd.accepted(bi, checks_b, last)
                     break
                 self.fallbacks += 1
+                if seam_b[0] == float("inf") and gave_up < self.MAX_GIVE_UPS:
+                    # the BPTT launch gave up waiting for its workgroups (see above): the same plan once more
+                    gave_up += 1
+                    self.launch_timeouts += 1
+                    if gave_up == self.MAX_GIVE_UPS:
+                        self._degrade_to_per_step_launches()
+                        pb = self._choose(ws, n, p0, s, fv, fr, bi)[3]
+                    self._value_chain_backward(ws, n, p0, s, fc, main, side, pb, None, tail=False)
+                    self._mark("backward_done")
+                    continue
                 if (self.last_cheap_bwd > 0 and not self._ladder_bwd.probing
                         and self._sudden(self._ladder_bwd, bi, False)):
                     # the 16-bit part of the warm-up may be what failed: the same plan again without it
@@ -1129,6 +1145,19 @@ class A2CEngine:
                ws["rewards"].view(s, n).t().contiguous())
         return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pv, pb), pr, status_host, full_calls=fc)
+
+    MAX_GIVE_UPS = 3   # attempts of one minibatch whose persistent launch may give up before the engine stops using them
+
+    def _degrade_to_per_step_launches(self):
+        """Persistent launches keep giving up (something else holds the CUs they need - another process on the same
+        GPU, a stream that keeps the device full): from here on this engine walks the chains with one launch per
+        step.  Slower by the launch overheads, but no workgroup waits for another."""
+        if self.persistent:
+            import warnings
+            warnings.warn("persistent chain launches gave up waiting for their workgroups %d times in one minibatch "
+                          "(see the [icrl] lines on stdout): this engine goes on with one launch per chain step"
+                          % self.MAX_GIVE_UPS, RuntimeWarning)
+            self.persistent = False
 
     def _word_tables(self, ws):
         """The chains' input projections for every WORD: table[w] = W_ih emb[w] + b (the value LSTM's with both

@@ -58,6 +58,7 @@ SIGNATURES = {
     "icrl_chain_pair_fwd_seg_f16x2": (c_int, [c_vp] * 5 + [c_int] * 8 + [c_vp] * 9),
     "icrl_chain_bwd_warm16_supported": (c_int, [c_int]),
     "icrl_lstm_chain_bwd_seg_warm16": (c_int, [c_vp] * 3 + [c_int] * 7 + [c_vp] * 4),
+    "icrl_chain_give_up_selftest": (c_int, [c_vp, c_vp, ctypes.c_uint, c_int, c_vp, c_vp]),
     "icrl_chain_pair_replay_check": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_replay_check_f16x2": (c_int, [c_vp] * 7 + [c_int] * 6 + [c_vp] * 4),
     "icrl_chain_pair_fwd_rows": (c_int, [c_vp] * 5 + [c_int] * 5 + [c_vp] * 7),
@@ -826,6 +827,15 @@ def chain_pair_replay_check(xproj_v, w_hh_v, saved_v, xproj_r, w_hh_r, b_hh_r, s
                                                  _ptr(_f32c(saved_r)), n, p0_v, p0_r, n_calls, full_calls, steps,
                                                  _ptr(_f32c(work_v)), _ptr(_f32c(work_r)), _ptr(_f32c(err)), _stream())
     _check(rc, "icrl_chain_pair_replay_check")
+
+
+def chain_give_up_selftest(flags, abort_words, epoch, wide, err):
+    """One bounded wait of the persistent launches on caller-supplied flags, then the kernel that reports a wait
+    that ran out (see icrl_chain_give_up_selftest)."""
+    assert flags.dtype == abort_words.dtype == torch.int32 and flags.numel() >= 32 and abort_words.numel() >= 4
+    assert err.dtype == torch.float32 and err.numel() >= 2
+    _check(load().icrl_chain_give_up_selftest(_ptr(flags), _ptr(abort_words), int(epoch), int(wide), _ptr(err), _stream()),
+           "icrl_chain_give_up_selftest")
 
 
 def chain_pair_fwd_rows(xproj_v, w_hh_v, xproj_r, w_hh_r, b_hh_r, n, p0_v, p0_r, n_calls, h_emit_v, saved_v, h_emit_r,

@@ -477,6 +477,18 @@ int icrl_chain_pair_replay_check_f16x2(const float* xproj_v, const float* w_hh_v
                                        const float* saved_r, int N, int p0_v, int p0_r, int n_calls, int full_calls,
                                        int steps, float* work_v, float* work_r, float* err, icrl_stream_t stream);
 
+/* The give-up path of the persistent launches, on its own (for the test-suite; no counterpart in the reference).
+ * Every wait inside a persistent launch is bounded by 20 ms of wall clock; the first wave whose wait runs out raises
+ * the launch's abort word, which releases every other waiter, and records next to it who it is (abort_words[1]:
+ * workgroup id), the step it waited at ([2]) and which producers of its row group had not reached that step ([3],
+ * bit i: producer i).  The kernel that follows every persistent launch turns a raised word into infinite seam errors
+ * (or a status word) and prints one line with those three numbers.  This entry point runs one such wait (16 flags,
+ * or 32 with `wide`) for `epoch` on caller-supplied flags - which never reach it unless the caller has set them - and
+ * then that follow-up kernel: err[0:2] = +inf if the wait ran out.  flags: 32 words; abort_words: 4 words, zeroed by
+ * the caller. */
+int icrl_chain_give_up_selftest(unsigned* flags, unsigned* abort_words, unsigned epoch, int wide, float* err,
+                                icrl_stream_t stream);
+
 /* One forward chain alone in the same persistent launch (the look-ahead decoder's value calls,
  * trainers.py:73-105, and the pre-training loops, trainers.py:125-199, run one chain at a time):
  * icrl_lstm_chain_fwd_seg / icrl_gru_chain_fwd_seg (models.py:133, 140-143 / 226, 231-233) with the same

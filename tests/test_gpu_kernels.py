@@ -1114,3 +1114,36 @@ def test_backward_chain_owner_computes_launch_on_the_f16_instruction(n, p0, call
         if first is not None:
             assert torch.equal(dg_new, first) and e_new == first_err
         first, first_err = dg_new, e_new
+
+
+# --------------------------------------------------------------------------- a wait that runs out
+@pytest.mark.parametrize("wide", [0, 1])
+def test_a_wait_that_runs_out_raises_the_abort_word_and_says_who_waited_for_whom(wide, capfd):
+    """The bounded wait of the persistent launches on flags that never arrive: after 20 ms it raises the abort word,
+    records the waiting workgroup, the step and the producers that were behind, and the follow-up kernel poisons the
+    error words and prints one line.  With every flag in place the same wait returns at once and nothing is raised."""
+    import time
+    producers = 32 if wide else 16
+    flags = torch.zeros(32, dtype=torch.int32, device="cuda")
+    flags[:producers] = 7
+    flags[3] = 6
+    flags[producers - 1] = 2
+    words = torch.zeros(4, dtype=torch.int32, device="cuda")
+    err = torch.zeros(2, device="cuda")
+    t0 = time.perf_counter()
+    hip.chain_give_up_selftest(flags, words, 7, wide, err)
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert [w & 0xffffffff for w in words.cpu().tolist()] == [1, 0, 7, (1 << 3) | (1 << (producers - 1))]
+    assert torch.isinf(err).all()
+    assert 0.015 < waited < 0.5, waited
+    out = capfd.readouterr().out
+    assert "[icrl] a persistent launch" in out and "step 7" in out and ("mask %08x" % ((1 << 3) | (1 << (producers - 1)))) in out
+    flags[:producers] = 7
+    words.zero_(); err.zero_()
+    t0 = time.perf_counter()
+    hip.chain_give_up_selftest(flags, words, 7, wide, err)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.01
+    assert words.cpu().tolist() == [0, 0, 0, 0] and not err.any()
+    assert "[icrl]" not in capfd.readouterr().out
