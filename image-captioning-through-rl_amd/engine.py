@@ -676,7 +676,7 @@ class A2CEngine:
         ws["rollout_id"] = ws.get("rollout_id", 0) + 1   # (what is derived from this rollout's outputs is kept under it)
         fused_step = self.E % 64 == 0 and self.pd == "f32"
         mode_s = mode if mode == hip.GREEDY else mode | hip.EMIT_DLOGITS
-        cell_done = False
+        cell_done = ws.pop("cell0_done", False)   # (step() has queued the first cell update already)
         h_cut = False   # the newest h is already in ws["h_p"] (left there by the sampler launch that computed it)
         wcat_ready = False
         k = -1
@@ -982,16 +982,16 @@ class A2CEngine:
         # the side stream beside the rollout, whose small launches leave most of the device idle
         ev_start = torch.cuda.Event()
         ev_start.record(main)
-        self._rollout_h0(ws, features)   # first on the critical path: queued before the other streams' launches
+        # first on the critical path, queued before the other streams' launches (the host needs 0.2 ms for those):
+        # h0 and, when the rollout starts at the first column, the first cell update
+        self._rollout_h0(ws, features)
         ws["h0_done"] = True             # (for the _rollout call below)
-        with torch.cuda.stream(side):
-            side.wait_event(ev_start)
-            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
-            hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
-            if backward:
-                self._value_head_vector(ws)
-            ev_feat = torch.cuda.Event()
-            ev_feat.record(side)
+        if self.E % 64 == 0 and self.pd == "f32":
+            self._rollout_cell(ws, 0, n, True)
+            ws["cell0_done"] = True
+        # then what the rollout's first round waits for (the policy network's per-word table and the pieces of its
+        # stacked weight), then the rollout itself; what is needed only after it - the image-feature products, the
+        # chains' per-word tables - is queued last and runs beside it all the same
         tables_on = self._check_stream() if self.concurrent else main
         ev_table_p = None
         with torch.cuda.stream(tables_on):
@@ -1000,17 +1000,27 @@ class A2CEngine:
                 self._policy_table(ws)
                 ev_table_p = torch.cuda.Event()
                 ev_table_p.record(tables_on)
+        self._rollout(ws, features, n, p0, s, uniforms, mode, ev_table=ev_table_p)
+        self._mark("rollout_done")
+        with torch.cuda.stream(side):
+            side.wait_event(ev_start)
+            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+            hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
+            if backward:
+                self._value_head_vector(ws)
+            ev_feat = torch.cuda.Event()
+            ev_feat.record(side)
+        with torch.cuda.stream(tables_on):
             self._word_tables(ws)
             ev_tables = torch.cuda.Event()
             ev_tables.record(tables_on)
-        self._rollout(ws, features, n, p0, s, uniforms, mode, ev_table=ev_table_p)
-        self._mark("rollout_done")
         main.wait_event(ev_feat)
         main.wait_event(ev_tables)
         ws["policy_early"] = False
         if backward and mode != hip.GREEDY:
             # (queued behind the forward chains' launch, beside which it runs: _chains_forward_loss)
             ws["order_pending"] = (n, (p0 - 1 + s) * n)
+            ws["g0_scales_pending"] = True
             ws["early_pending"] = bool(self.concurrent)
         last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
@@ -1035,6 +1045,9 @@ class A2CEngine:
             # (G0 . W is queued behind the forward chains' launch on the third stream whichever way the policy LSTM's
             # BPTT is run: it starts when the chains end, beside the heads and the loss, and what flows into the LSTM
             # outputs is ready when the value chain's BPTT is)
+            # (with the policy BPTT as one launch the third stream carries the vocabulary products on the path to it:
+            # the token order, which only the embedding gradients at the end of the step read, is queued behind them)
+            ws["order_late"] = bool(tail and self.concurrent)
             ev_seam, ev_replay, replay_steps = self._chains_forward_loss(ws, features, n, p0, s, fc, backward, main, side,
                                                                          pv, pr)
             if with_bwd:
@@ -1351,8 +1364,11 @@ class A2CEngine:
             else:
                 self._early_now(ws, n, p0, s, main)
                 hip.chain_pair_fwd_seg(*pair_args, **pair_opts)
-        if "order_pending" in ws:
+        ws["ev_tok"] = ev_tok
+        if "order_pending" in ws and not ws.get("order_late"):
             self._order_tokens(ws, *ws.pop("order_pending"), main, side, after=ev_tok)
+        if "g0_scales_pending" in ws:
+            ws.pop("g0_scales_pending")
             if self.vgd == "f16x2" and self.concurrent:
                 # G0's scales (a pass over the [rows, V] matrix for the per-word ones): beside the forward chains
                 with torch.cuda.stream(self._check_stream()):
@@ -1566,7 +1582,7 @@ class A2CEngine:
             # first get the device first, and with two vocabulary-sized products (36 KB of LDS per workgroup, four
             # per CU) in front of it the chain's persistent launch (84 KB per workgroup) found no CU to start on for
             # 0.9 ms (kernel trace: BPTT from 4.43 ms into the step, against 3.60 ms in this order)
-            ev_dhall, ev_vocab = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
+            ev_dhall, rest_of_third_stream = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
 
         def policy_bptt():
             # the policy LSTM's backward-through-time: one persistent launch
@@ -1585,6 +1601,7 @@ class A2CEngine:
             # right behind the value chain's launch (measured: behind the value network's weight gradients instead,
             # 5.70 against 5.45 ms a minibatch)
             ev_pbptt = policy_bptt()
+            ev_vocab = rest_of_third_stream(ev_pbptt)
         if plan[0] == "segmented":
             # every word the host reads back (backward seam error, the chain kernels' status words) is final here
             ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
@@ -1649,6 +1666,8 @@ class A2CEngine:
             # by 0.7 ms in a kernel trace)
             with torch.cuda.stream(side):
                 side.wait_event(ev_pbptt)
+                if ws.get("ev_order") is not None:
+                    side.wait_event(ws.pop("ev_order"))
                 self._policy_weight_grads(ws, features, n, p0, s)
                 side.wait_event(ev_vocab)
                 self._mark("side:policy_bwd_done")
@@ -1737,7 +1756,9 @@ class A2CEngine:
         chain's BPTT (see _tail_ok).  Third stream: U = G0 . W (unless an earlier attempt of this minibatch has
         formed it), what flows into the LSTM outputs (coef * U), coef * Hs, then the value head's weight
         gradients.  Side stream: the vocabulary matrix's gradients G0^T . (coef * Hs) and sum_r coef[r] G0[r, :].
-        Returns (event after which ws["dHall"] is complete, event after which the vocabulary gradients are)."""
+        Returns (event after which ws["dHall"] is complete, a function that queues the rest of the third stream's work
+        behind the event it is given - the policy BPTT launch's - and returns the event after which the vocabulary
+        gradients are complete)."""
         P, gP = self.P, self.gP
         coef = ws["dlogp"]
         G0 = ws["dlogits"].view(s * n, self.vocab)
@@ -1763,23 +1784,42 @@ class A2CEngine:
             # both BPTT launches, when nothing was left to run beside them
             hip.scale_rows(Hs, coef, ws["HsC"])
             self._vocab_weight_grad(ws, G0, ws["scratch_check"])
+
+        def after_policy_bptt(ev_pbptt):
+            """The rest of the third stream's work, released behind the policy LSTM's BPTT launch: that launch needs
+            every CU, so it starts only once the other streams have drained, and these small launches (queued right
+            behind the vocabulary weight gradient they held it back by 0.35 ms in a kernel trace) do not need to
+            run before it."""
+            with torch.cuda.stream(check):
+                check.wait_event(ev_pbptt)
+                late_check_work()
+            return ws.pop("ev_vocab_late")
+
+        def late_check_work():
             hip.colsum(G0, gP["linear2vocab.bias"], scratch=ws["cs_check"], row_scale=coef)
             ev_vocab = torch.cuda.Event()
             ev_vocab.record(check)
+            ws["ev_vocab_late"] = ev_vocab
             self._mark("check:vocab_grads_done")
+            if "order_pending" in ws:
+                n_rows = ws.pop("order_pending")
+                if any(g is not None and g.get(k) is not None for g, k in
+                       ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
+                    hip.token_order(ws["tokT"].view(-1), 1, n_rows[1], self._emb_vocab(), ws["emb_work"])
+                    ws["ev_order"] = ws["ev_order_done"] = torch.cuda.Event()
+                    ws["ev_order"].record(check)
             pending = ws.pop("head_grads_pending", None)
             if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
                 self._value_head_weight_grads(ws, *pending, ws["scratch_check"], ws["cs_check"])
                 ws["ev_head_grads"] = torch.cuda.Event()
                 ws["ev_head_grads"].record(check)
+
         with torch.cuda.stream(side):
             side.wait_event(ev_loss)
             self._mark("side:policy_bwd_start")
-            if ws.get("ev_order") is not None:
-                side.wait_event(ws.pop("ev_order"))
             if ws.get("X_pending"):   # the embedding rows of the steps that took their input side from the per-word table
                 t_steps = p0 - 1 + s
                 hip.gather_rows(P["caption_embedding.weight"], ws["tokT"].view(-1), 1, t_steps * n,
                                 ws["X"].view(t_steps * n, -1))
                 ws["X_pending"] = False
-        return ev_dhall, ev_vocab
+        return ev_dhall, after_policy_bptt
