@@ -213,6 +213,8 @@ def main():
                     help="the rollout's per-round vocabulary/gate product (default: the engine's, f16x2)")
     ap.add_argument("--chain-arith", default=None, choices=("f32", "f16x2"),
                     help="recurrent products of the forward chains' persistent launch (default: the engine's)")
+    ap.add_argument("--value-bptt-first", action="store_true",
+                    help="queue the value chain's BPTT ahead of the policy LSTM's (the order before the reordered schedule)")
     ap.add_argument("--max-streams", type=int, default=None, choices=(3, 4),
                     help="streams the engine uses, the caller's included (default: the engine's)")
     ap.add_argument("--no-late-policy-bptt", action="store_true",
@@ -264,6 +266,8 @@ def main():
     engine = trainers.build_engine(a2c, rew, **engine_opts)
     if args.max_streams is not None:
         engine.max_streams = args.max_streams
+    if args.value_bptt_first:
+        engine.policy_bptt_first = False
     feats, caps = syn.make_minibatch(n, vocab, caplen, fdim, rank)  # a different shard per rank
     feats_d = torch.from_numpy(feats).to(dev)
     prefix_d = torch.from_numpy(caps[:, :1]).to(dev)

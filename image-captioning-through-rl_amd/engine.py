@@ -187,7 +187,7 @@ class A2CEngine:
                  concurrent=True, chain_mode="auto", segments=None, persistent=True, entropy=False,
                  chain_semantics="batch", collapse_replays=True, max_segments=512, policy_dtype="f32",
                  frozen_reward=False, warm16=True, warm16_backward=False, grad_products="f16x2", late_policy_bptt=True,
-                 chain_arith="f16x2", rollout_arith="f16x2",
+                 chain_arith="f16x2", rollout_arith="f16x2", policy_bptt_first=True,
                  warmups=(48, 64, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320, 384, 448, 512, 640, 768, 1024,
                           1280, 1536, 2048, 2560, 3072, 4096, 6144, 8192), first_warmup=96):
         """*_params: dict state_dict-name -> contiguous float32 CUDA tensor (the live
@@ -263,6 +263,10 @@ class A2CEngine:
         # replay check (see _replay_stream); side_stream() hands the side stream to a caller that wants its
         # collective queued there instead of on yet another stream
         self.max_streams = 3
+        # order of the two BPTT launches when the policy LSTM's is one launch: the policy LSTM's first (0.2 ms alone on
+        # the device), so that the weight gradients of BOTH networks' other layers and the replay check have the whole
+        # of the value chain's BPTT (1.3 ms on half the CUs) to run beside (see _value_chain_backward)
+        self.policy_bptt_first = bool(policy_bptt_first)
         # every chain starts at the first rung of at least first_warmup steps (freshly initialised networks
         # pass there); shorter rungs are reached only by probing down
         start = next((i for i, w in enumerate(self.warmups) if w >= first_warmup), len(self.warmups) - 1)
@@ -367,6 +371,9 @@ class A2CEngine:
                 ws["work_cv"] = f32(hip.chain_seg_workspace_floats(s))
                 ws["work_cr"] = f32(hip.chain_seg_workspace_floats(s))
         ws["segments"] = k
+        # scale of an operand bounded by 1 in the two-piece products (see _unit_scale): filled here, on the caller's
+        # stream before the step's other streams branch off, because products on several streams read it
+        ws["sc16_unit"] = torch.full((max(4096, 4 * H),), 16384.0, dtype=torch.float32, device=dev)
         if s == 1 or not self.collapse:
             self._chain_capacity(ws, tv, 0)
         self._ws[key] = ws
@@ -658,7 +665,7 @@ class A2CEngine:
             torch.add(bias, bias2, out=bsum)
         hip.gemm_f16x2(ep, ed, wp, wd, out, emb.shape[1], bias=bsum if bias2 is not None else bias)
 
-    def _rollout(self, ws, features, n, p0, s, uniforms, mode, ev_table=None):
+    def _rollout(self, ws, features, n, p0, s, uniforms, mode, ev_table=None, between=None):
         """Policy rollout (models.py:71-84 run incrementally; trainers.py:443-458): LSTM state carried
         from column to column, only the newest position projected to the vocabulary and sampled (or
         arg-maxed, or scored against the forced token).  With ev_table (the event after which _policy_table's
@@ -704,14 +711,23 @@ class A2CEngine:
                     if hip.PROFILE is None:
                         # every remaining round of this kind by one call into the library (the same launches; a host
                         # call per launch, 50 us a round, is more than the two launches take on the device)
-                        rounds = t_steps - 1 - k
-                        hip.policy_rollout_rounds(
-                            ws["Wcat_p"], ws["Wcat_d"], ws["bcat"], ws["h_p"], ws["h_d"], ext, n, V, self._padded_vocab(),
-                            rounds, mode_s, tokT[k + 1:k + 1 + rounds], ws["logp"][st:st + rounds], ws["table_p"],
-                            gates[k + 1:k + 1 + rounds], Cb[k + 1:k + 2 + rounds], Hb[k + 2:k + 2 + rounds],
-                            uniforms=None if uniforms is None else uniforms[st * n:(st + rounds) * n],
-                            probs=ws["dlogits"][st:st + rounds] if mode != hip.GREEDY else None,
-                            entropy=ws["entropy"][st:st + rounds] if (self.want_entropy and mode != hip.GREEDY) else None)
+                        # (`between`: what the caller wants queued on other streams once the rollout is under way - the
+                        # device takes launches up in about the order the host queues them, so work queued before the
+                        # rollout delays its first round and work queued after all of it starts when it ends)
+                        total = t_steps - 1 - k
+                        for rounds in ((min(2, total), total - min(2, total)) if between is not None else (total,)):
+                            if rounds > 0:
+                                hip.policy_rollout_rounds(
+                                    ws["Wcat_p"], ws["Wcat_d"], ws["bcat"], ws["h_p"], ws["h_d"], ext, n, V, self._padded_vocab(),
+                                    rounds, mode_s, tokT[k + 1:k + 1 + rounds], ws["logp"][st:st + rounds], ws["table_p"],
+                                    gates[k + 1:k + 1 + rounds], Cb[k + 1:k + 2 + rounds], Hb[k + 2:k + 2 + rounds],
+                                    uniforms=None if uniforms is None else uniforms[st * n:(st + rounds) * n],
+                                    probs=ws["dlogits"][st:st + rounds] if mode != hip.GREEDY else None,
+                                    entropy=ws["entropy"][st:st + rounds] if (self.want_entropy and mode != hip.GREEDY) else None)
+                                k, st = k + rounds, st + rounds
+                            if between is not None:
+                                between()
+                                between = None
                         k, cell_done, h_cut = t_steps - 2, True, True
                         continue
                     hip.gemm_f16x2(ws["h_p"], ws["h_d"], ws["Wcat_p"], ws["Wcat_d"], ext, H, bias=ws["bcat"])
@@ -739,6 +755,8 @@ class A2CEngine:
         # the embedding rows of the steps that took their input side from the table are gathered when the
         # backward pass asks for them
         ws["X_pending"] = ev_table is not None
+        if between is not None:
+            between()
 
     def _rollout_h0(self, ws, features):
         """h0 = cnn2linear(features) (models.py:71): a 64-tile output with a long k, first on the step's critical
@@ -1000,27 +1018,33 @@ class A2CEngine:
                 self._policy_table(ws)
                 ev_table_p = torch.cuda.Event()
                 ev_table_p.record(tables_on)
-        self._rollout(ws, features, n, p0, s, uniforms, mode, ev_table=ev_table_p)
+        events = {}
+
+        def beside_the_rollout():
+            with torch.cuda.stream(side):
+                side.wait_event(ev_start)
+                hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
+                hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
+                if backward:
+                    self._value_head_vector(ws)
+                events["feat"] = torch.cuda.Event()
+                events["feat"].record(side)
+            with torch.cuda.stream(tables_on):
+                self._word_tables(ws)
+                if backward:
+                    self._parameter_scales(ws)
+                events["tables"] = torch.cuda.Event()
+                events["tables"].record(tables_on)
+
+        self._rollout(ws, features, n, p0, s, uniforms, mode, ev_table=ev_table_p, between=beside_the_rollout)
         self._mark("rollout_done")
-        with torch.cuda.stream(side):
-            side.wait_event(ev_start)
-            hip.gemm(features, R["visual_embed.weight"], ws["ve"], bias=R["visual_embed.bias"])
-            hip.gemm(features, V["linear1.weight"][:, :self.F], ws["U"], bias=V["linear1.bias"])
-            if backward:
-                self._value_head_vector(ws)
-            ev_feat = torch.cuda.Event()
-            ev_feat.record(side)
-        with torch.cuda.stream(tables_on):
-            self._word_tables(ws)
-            ev_tables = torch.cuda.Event()
-            ev_tables.record(tables_on)
+        ev_feat, ev_tables = events["feat"], events["tables"]
         main.wait_event(ev_feat)
         main.wait_event(ev_tables)
         ws["policy_early"] = False
         if backward and mode != hip.GREEDY:
             # (queued behind the forward chains' launch, beside which it runs: _chains_forward_loss)
             ws["order_pending"] = (n, (p0 - 1 + s) * n)
-            ws["g0_scales_pending"] = True
             ws["early_pending"] = bool(self.concurrent)
         last = len(self.warmups)   # ladder index of the exact kernels
         fv, fr, bi = (min(lad.first, last) for lad in (self._ladder_fv, self._ladder_fr, self._ladder_bwd))
@@ -1048,10 +1072,17 @@ class A2CEngine:
             # (with the policy BPTT as one launch the third stream carries the vocabulary products on the path to it:
             # the token order, which only the embedding gradients at the end of the step read, is queued behind them)
             ws["order_late"] = bool(tail and self.concurrent)
+            ws["defer_replay"] = bool(tail and self.policy_bptt_first)
+            ws.pop("replay_deferred", None)
+            ws.pop("ev_replay_late", None)
             ev_seam, ev_replay, replay_steps = self._chains_forward_loss(ws, features, n, p0, s, fc, backward, main, side,
                                                                          pv, pr)
             if with_bwd:
                 self._backward(ws, features, n, p0, s, fc, main, side, pb, tail)
+            if "replay_deferred" in ws:       # nobody has queued the replay check yet
+                ev_replay = ws.pop("replay_deferred")()
+            elif "ev_replay_late" in ws:
+                ev_replay = ws.pop("ev_replay_late")
             self._mark("backward_done")
             seg_v, seg_r = pv[0] == "segmented", pr[0] == "segmented"
             checks_v, checks_r = [], []
@@ -1227,7 +1258,7 @@ class A2CEngine:
         per-row coefficient)."""
         rows = self._g0_scales(ws, G0, False)[0] if self.vgd == "f16x2" else None
         self._pgemm(ws, "uvoc", G0, self.P["linear2vocab.weight"], ws["Uvocab"], scratch, self.vgd, b_kmajor=True, shared=True,
-                    a_scale=rows)
+                    a_scale=rows, b_scale=ws.get("psc_wvoc") if self.vgd == "f16x2" else None)
 
     def _vocab_weight_grad(self, ws, G0, scratch):
         """linear2vocab.weight's gradient G0^T . (coef * Hs) on the current stream."""
@@ -1296,6 +1327,7 @@ class A2CEngine:
         self._chain_capacity(ws, tv, tr if collapsed else 0)
         tok_flat = ws["tokT"].view(-1)
         ws["Xv_gathered"] = False     # set below when this attempt gathers the value network's embedding rows early
+        ws["psc_hbuf"] = None
         seg, seg_r, rows = plan[0] == "segmented", plan_r[0] == "segmented", plan[0] == "rows"
         keep = backward or collapsed      # the value chain's activations: for the BPTT, and for the replay check
 
@@ -1342,12 +1374,15 @@ class A2CEngine:
                                     ws["status"][0:1], persistent=self.persistent and hip.chain_pair_supported(n))
         elif pair and self.chain_arith == "f16x2" and hip.chain_f16x2_supported(plan[1]):
             self.last_cheap = (0, 0)
-            self._early_now(ws, n, p0, s, main)
             hip.chain_pair_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
                                    R["rewrnn.gru.bias_hh_l0"], n, p0, p0 + 1, s, plan[1], plan[2], ws["hv"],
                                    ws["saved"] if keep else None, ws["hr"], ws["work_v"], ws["work_r"], ws["seam"][0:2],
                                    ws["seam"][2:4], warmup_r=plan_r[2], full_calls=fc,
                                    saved_r=ws["saved_r"] if collapsed else None, arith="f16x2")
+            # G0 . W behind the launch, not beside it: the f16 pair holds every CU's registers, so what is queued beside
+            # it either waits for it to end anyway or - when it gets to the CUs first, as a 1 520-workgroup product did
+            # in a kernel trace - keeps the pair's workgroups from becoming resident (pair 0.82 -> 1.82 ms)
+            self._early_now(ws, n, p0, s, main)
         elif pair:
             cheap = self._note_cheap(plan, plan_r)
             pair_args = (ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["XPr"], R["rewrnn.gru.weight_hh_l0"],
@@ -1367,18 +1402,14 @@ class A2CEngine:
         ws["ev_tok"] = ev_tok
         if "order_pending" in ws and not ws.get("order_late"):
             self._order_tokens(ws, *ws.pop("order_pending"), main, side, after=ev_tok)
-        if "g0_scales_pending" in ws:
-            ws.pop("g0_scales_pending")
-            if self.vgd == "f16x2" and self.concurrent:
-                # G0's scales (a pass over the [rows, V] matrix for the per-word ones): beside the forward chains
-                with torch.cuda.stream(self._check_stream()):
-                    self._check_stream().wait_event(ev_tok)
-                    self._g0_scales(ws, ws["dlogits"].view(s * n, self.vocab), True)
         if pair and backward:
             # the value network's embedding rows, which only its input-side weight gradient reads: gathered
             # beside the chains instead of at the end of the step (the side stream's later events cover it)
             with torch.cuda.stream(side):
                 hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
+                if self.vgd == "f16x2":
+                    # and the column scales of the policy LSTM's outputs for its recurrent weight gradient
+                    ws["psc_hbuf"] = self._scale_of(ws, "p_hbuf", ws["Hbuf"][:p0 - 1 + s].view((p0 - 1 + s) * n, H), True)
             ws["Xv_gathered"] = True
         ev_seam = None
         if pair:
@@ -1404,20 +1435,30 @@ class A2CEngine:
             ev_chains = torch.cuda.Event()
             ev_chains.record(main)
             check = self._replay_stream() if self.concurrent else main
-            with torch.cuda.stream(check):
-                check.wait_event(ev_chains)
-                if not pair:
-                    check.wait_event(ev_gru)
-                hip.chain_pair_replay_check(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["XPr"],
-                                            R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], ws["saved_r"],
-                                            n, p0, p0 + 1, s, fc, replay_steps, ws["work_cv"], ws["work_cr"],
-                                            ws["ctl"][6:8],
-                                            arith="f16x2" if (self.chain_arith == "f16x2" and self.persistent
-                                                              and hip.chain_f16x2_supported(s - fc)) else "f32")
-                ws["replay_host"].copy_(ws["ctl"][6:8], non_blocking=True)
-                ev_replay = torch.cuda.Event()
-                ev_replay.record(check)
-                self._mark("check:replay_done")
+
+            def launch_replay(after=None):
+                with torch.cuda.stream(check):
+                    check.wait_event(ev_chains)
+                    if after is not None:
+                        check.wait_event(after)
+                    if not pair:
+                        check.wait_event(ev_gru)
+                    hip.chain_pair_replay_check(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], ws["saved"], ws["XPr"],
+                                                R["rewrnn.gru.weight_hh_l0"], R["rewrnn.gru.bias_hh_l0"], ws["saved_r"],
+                                                n, p0, p0 + 1, s, fc, replay_steps, ws["work_cv"], ws["work_cr"],
+                                                ws["ctl"][6:8],
+                                                arith="f16x2" if (self.chain_arith == "f16x2" and self.persistent
+                                                                  and hip.chain_f16x2_supported(s - fc)) else "f32")
+                    ws["replay_host"].copy_(ws["ctl"][6:8], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(check)
+                    self._mark("check:replay_done")
+                return ev
+
+            if ws.get("defer_replay"):
+                ws["replay_deferred"] = launch_replay   # (the backward pass queues it behind the policy BPTT's launch)
+            else:
+                ev_replay = launch_replay()
         w1 = V["linear1.weight"]
         hip.gemm(ws["hv"].view(s * n, H), w1[:, self.F:], ws["Y"])
         hip.value_head_fwd(ws["Y"], ws["U"], V["linear2.weight"], V["linear2.bias"], s * n, n, ws["values"])
@@ -1497,6 +1538,36 @@ class A2CEngine:
         hip.absmax_scales(x, buf[1], col_scale=buf[0] if cols else None, row_scale=None if cols else buf[0])
         return buf[0]
 
+    def _scales_of(self, ws, key, x):
+        """(row scales, column scales) of x from ONE pass (an operand that enters one product along its rows and
+        another along its columns: the gate gradients)."""
+        r, c = x.shape
+        buf = ws.get("sc16_" + key)
+        if buf is None or buf[0].numel() < r or buf[1].numel() < c:
+            buf = ws["sc16_" + key] = (torch.empty(r, dtype=torch.float32, device=self.device),
+                                       torch.empty(c, dtype=torch.float32, device=self.device),
+                                       torch.empty(r + c, dtype=torch.int32, device=self.device))
+        hip.absmax_scales(x, buf[2], row_scale=buf[0], col_scale=buf[1])
+        return buf[0], buf[1]
+
+    def _unit_scale(self, ws, count):
+        """The scale of an operand whose entries lie in (-1, 1) (an LSTM's hidden state): 2^14 for every row, no pass."""
+        t = ws["sc16_unit"]
+        assert t.numel() >= count
+        return t
+
+    def _parameter_scales(self, ws):
+        """Scales that depend on the parameters alone, computed beside the rollout (current stream): the columns of the
+        embedding tables (a bound for the columns of any set of gathered rows), of the LSTMs' input weights and of the
+        vocabulary matrix, as the backward pass's two-piece products take them."""
+        if self.gd != "f16x2" and self.vgd != "f16x2":
+            return
+        P, V = self.P, self.V
+        for key, w in (("embP", P["caption_embedding.weight"]), ("wihP", P["lstm.weight_ih_l0"]),
+                       ("wvoc", P["linear2vocab.weight"]), ("embV", V["valrnn.caption_embedding.weight"]),
+                       ("wihV", V["valrnn.lstm.weight_ih_l0"])):
+            ws["psc_" + key] = self._scale_of(ws, "p_" + key, w, True)
+
     def _pgemm(self, ws, tag, a, b, out, scratch, dtype, a_kmajor=False, b_kmajor=False, shared=False, a_scale=None,
                b_scale=None):
         """A product of the backward pass in the arithmetic `dtype` (hipabi.gemm_auto).  With "f16x2" the operands'
@@ -1537,7 +1608,8 @@ class A2CEngine:
         hip.gemm_auto(dvalue, ws["Y"], gV["linear2.weight"], scratch, a_kmajor=True, b_kmajor=True)  # dw2 = dvalue^T Y
         hip.colsum(dvalue, gV["linear2.bias"], scratch=cs)
         gw1 = gV["linear1.weight"]
-        self._pgemm(ws, "gw1h", dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, self.gd, a_kmajor=True, b_kmajor=True)
+        self._pgemm(ws, "gw1h", dY, ws["hv"].view(s * n, H), ws["gw1h"], scratch, self.gd, a_kmajor=True, b_kmajor=True,
+                    b_scale=self._unit_scale(ws, H) if self.gd == "f16x2" else None)
         gw1[:, self.F:].copy_(ws["gw1h"])
         hip.colsum(dY.view(s, n * 512), ws["dYsum"].view(-1), scratch=cs)
         hip.gemm(ws["dYsum"], features, gw1[:, :self.F], a_kmajor=True, b_kmajor=True)
@@ -1553,36 +1625,32 @@ class A2CEngine:
         tok_flat = ws["tokT"].view(-1)
         saved, dgv = ws["saved"][:tv], ws["dgv"][:tv]
         tail = tail and ev_loss is not None
-        if plan[0] == "rows":
-            hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
-                                    ws["work_v"], ws["status"][2:3],
-                                    persistent=self.persistent and hip.chain_pair_supported(n))
-        elif plan[0] == "segmented" and self._bwd_f16x2(plan[1]):
-            # owner-computes launch on the f16 matrix instruction (a workspace of its own: the exchanged partial tiles)
-            self.last_cheap_bwd = 0
-            key = "work_b%d" % plan[1]
-            if key not in ws:
-                ws[key] = torch.empty(hip.chain_bwd_f16x2_workspace_floats(plan[1]), dtype=torch.float32, device=self.device)
-            hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
-                                   dgv, ws[key], ws["seam"][4:6], full_calls=fc, arith="f16x2")
-        elif plan[0] == "segmented":
-            self.last_cheap_bwd = self._cheap_bwd(plan)
-            hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
-                                   dgv, ws["work_v"], ws["seam"][4:6], full_calls=fc,
-                                   persistent=self.persistent and hip.chain_pair_supported(plan[1]),
-                                   cheap=self.last_cheap_bwd)
-        else:
-            assert fc == s
-            hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
-                               ws["sync_v"], ws["status"][2:3])
+        def launch_value_chain():
+            if plan[0] == "rows":
+                hip.lstm_chain_bwd_rows(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
+                                        ws["work_v"], ws["status"][2:3],
+                                        persistent=self.persistent and hip.chain_pair_supported(n))
+            elif plan[0] == "segmented" and self._bwd_f16x2(plan[1]):
+                # owner-computes launch on the f16 matrix instruction (a workspace of its own: the exchanged partial tiles)
+                self.last_cheap_bwd = 0
+                key = "work_b%d" % plan[1]
+                if key not in ws:
+                    ws[key] = torch.empty(hip.chain_bwd_f16x2_workspace_floats(plan[1]), dtype=torch.float32, device=self.device)
+                hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
+                                       dgv, ws[key], ws["seam"][4:6], full_calls=fc, arith="f16x2")
+            elif plan[0] == "segmented":
+                self.last_cheap_bwd = self._cheap_bwd(plan)
+                hip.lstm_chain_bwd_seg(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, plan[1], plan[2],
+                                       dgv, ws["work_v"], ws["seam"][4:6], full_calls=fc,
+                                       persistent=self.persistent and hip.chain_pair_supported(plan[1]),
+                                       cheap=self.last_cheap_bwd)
+            else:
+                assert fc == s
+                hip.lstm_chain_bwd(V["valrnn.lstm.weight_hh_l0"], saved, ws["d_emit"], n, p0, s, dgv,
+                                   ws["sync_v"], ws["status"][2:3])
 
-        self._mark("value_chain_bwd_done")
-        if tail:
-            # queued BEHIND the chain's launch although it waits for the loss only: launches that the host queues
-            # first get the device first, and with two vocabulary-sized products (36 KB of LDS per workgroup, four
-            # per CU) in front of it the chain's persistent launch (84 KB per workgroup) found no CU to start on for
-            # 0.9 ms (kernel trace: BPTT from 4.43 ms into the step, against 3.60 ms in this order)
-            ev_dhall, rest_of_third_stream = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
+        pfirst = tail and self.policy_bptt_first
+        ev_dhall = rest_of_third_stream = ev_pbptt = ev_vocab = None
 
         def policy_bptt():
             # the policy LSTM's backward-through-time: one persistent launch
@@ -1597,16 +1665,61 @@ class A2CEngine:
             ev = torch.cuda.Event()
             ev.record(main)
             return ev
-        if tail:
+
+        if pfirst:
+            # The policy LSTM's BPTT FIRST: its inputs (coef * G0 . W) are ready soon after the loss, it needs the whole
+            # device for 0.25 ms either way, and with it out of the way the policy network's weight gradients, the
+            # vocabulary weight gradient and the replay check all run beside the value chain's BPTT (which leaves half
+            # of the CUs free) instead of after it.
+            ev_dhall, rest_of_third_stream = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side, vocab_later=True)
+            ev_pbptt = policy_bptt()
+        launch_value_chain()
+        self._mark("value_chain_bwd_done")
+
+        def read_back():
+            # every word the host reads back (backward seam error, the chain kernels' status words) is final here.
+            # Queued before the other streams' work that follows in this function: a device-to-host copy was seen to
+            # start only once everything the host had queued before it, on any stream, had been dispatched (1.1 ms
+            # after the BPTT it follows, in a kernel trace, with the policy network's weight gradients queued first)
+            if plan[0] == "segmented":
+                ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
+                ws["ev_ctl"] = torch.cuda.Event()
+                ws["ev_ctl"].record(main)
+
+        if pfirst:
+            # In the order the device is to take them up (it dispatches roughly in the order of submission, and a
+            # launch that is ready but finds no room holds back what was submitted after it, on any stream): the
+            # read-back, the replay check (64 half-CU workgroups: they fit beside the BPTT's 128 CUs only while the
+            # products have not filled the rest), the policy network's weight gradients, the vocabulary weight
+            # gradient and the third stream's small launches; the value network's weight gradients follow on the main
+            # stream.
+            read_back()
+            if "replay_deferred" in ws:
+                ws["ev_replay_late"] = ws.pop("replay_deferred")(ev_pbptt)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_pbptt)
+                if "order_pending" in ws:
+                    n_rows = ws.pop("order_pending")
+                    if any(g is not None and g.get(k) is not None for g, k in
+                           ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
+                        hip.token_order(ws["tokT"].view(-1), 1, n_rows[1], self._emb_vocab(), ws["emb_work"])
+                        ws["ev_order_done"] = torch.cuda.Event()
+                        ws["ev_order_done"].record(side)
+                self._policy_weight_grads(ws, features, n, p0, s)
+            ev_vocab = rest_of_third_stream(ev_pbptt)
+        elif tail:
+            # queued BEHIND the chain's launch although it waits for the loss only: launches that the host queues
+            # first get the device first, and with two vocabulary-sized products (36 KB of LDS per workgroup, four
+            # per CU) in front of it the chain's persistent launch (84 KB per workgroup) found no CU to start on for
+            # 0.9 ms (kernel trace: BPTT from 4.43 ms into the step, against 3.60 ms in this order)
+            ev_dhall, rest_of_third_stream = self._policy_backward_beside_chain(ws, n, p0, s, ev_loss, side)
             # right behind the value chain's launch (measured: behind the value network's weight gradients instead,
             # 5.70 against 5.45 ms a minibatch)
             ev_pbptt = policy_bptt()
+            read_back()
             ev_vocab = rest_of_third_stream(ev_pbptt)
-        if plan[0] == "segmented":
-            # every word the host reads back (backward seam error, the chain kernels' status words) is final here
-            ws["ctl_host"].copy_(ws["ctl"][4:12], non_blocking=True)
-            ws["ev_ctl"] = torch.cuda.Event()
-            ws["ev_ctl"].record(main)
+        else:
+            read_back()
         # ---- side stream: the policy network's BPTT beside the value chain
         ev_side = None
 
@@ -1634,30 +1747,42 @@ class A2CEngine:
         back = n if plan[0] == "rows" else 1
         if tv > back:
             h_prev = saved.view(tv, 6 * H)[:tv - back, 5 * H:]
+            f16 = self.gd == "f16x2"
+            # one pass for the row and column scales of the gate gradients when the input-side products below read
+            # the same matrix (else the positions of this product alone: the matrix may hold rows no launch wrote)
+            shared_pass = f16 and fc == 1 and p0 == 1 and s > 1
+            dg_rows, dg_cols = self._scales_of(ws, "vdg", dgv) if shared_pass else (None, None)
             self._pgemm(ws, "vhh", dgv[back:], h_prev, gV["valrnn.lstm.weight_hh_l0"], sm, self.gd, a_kmajor=True,
-                        b_kmajor=True)
+                        b_kmajor=True, a_scale=dg_cols, b_scale=self._unit_scale(ws, H) if f16 else None)
         else:
             gV["valrnn.lstm.weight_hh_l0"].zero_()
         self._mark("value_wgrads_done")
         # ---- then the value network's input-side gradients (the policy network's backward pass outlasts the
         # chain's on the side stream, so these follow the chain on this one)
+        same = fc == 1 and p0 == 1 and s > 1 and tv > back and self.gd == "f16x2"
         if fc == 1 and p0 == 1 and s > 1:
             dgsum = dgv          # every column occurs once in the chain: nothing to sum over calls
         else:
             dgsum = ws["dGsum"]
             hip.chain_fold_calls(dgv, n, p0, s, 4 * H, dgsum, full_calls=fc)
+        if self.gd == "f16x2":
+            sum_rows, sum_cols = (dg_rows, dg_cols) if same else self._scales_of(ws, "vdgs", dgsum[:lv * n])
+            emb_cols, wih_cols = ws.get("psc_embV"), ws.get("psc_wihV")
+        else:
+            sum_rows = sum_cols = emb_cols = wih_cols = None
         if ev_loss is not None and not ws.pop("Xv_gathered", False):
             # the A2C step took its input projections from the per-word table: gather x now
             hip.gather_rows(V["valrnn.caption_embedding.weight"], tok_flat, 1, lv * n, ws["Xv"])
         self._pgemm(ws, "vih", dgsum[:lv * n], ws["Xv"][:lv * n], gV["valrnn.lstm.weight_ih_l0"], sm, self.gd, a_kmajor=True,
-                    b_kmajor=True)
+                    b_kmajor=True, a_scale=sum_cols, b_scale=emb_cols)
         hip.colsum(dgsum, gV["valrnn.lstm.bias_ih_l0"], rows=lv * n, scratch=ws["cs_main"])
         gV["valrnn.lstm.bias_hh_l0"].copy_(gV["valrnn.lstm.bias_ih_l0"])
         g_emb = gV.get("valrnn.caption_embedding.weight")
         if g_emb is not None:
             if ws.get("ev_order_done") is not None:
                 main.wait_event(ws["ev_order_done"])
-            self._pgemm(ws, "vdx", dgsum[:lv * n], V["valrnn.lstm.weight_ih_l0"], ws["dXv"][:lv * n], sm, self.gd, b_kmajor=True)
+            self._pgemm(ws, "vdx", dgsum[:lv * n], V["valrnn.lstm.weight_ih_l0"], ws["dXv"][:lv * n], sm, self.gd, b_kmajor=True,
+                        a_scale=sum_rows, b_scale=wih_cols)
             hip.embedding_grad(g_emb, lv * n, ws["dXv"], ws["emb_work"])
         self._mark("value_input_grads_done")
         if tail:
@@ -1665,10 +1790,11 @@ class A2CEngine:
             # order the host queued them across streams (queued first, these held the main stream's first product back
             # by 0.7 ms in a kernel trace)
             with torch.cuda.stream(side):
-                side.wait_event(ev_pbptt)
-                if ws.get("ev_order") is not None:
-                    side.wait_event(ws.pop("ev_order"))
-                self._policy_weight_grads(ws, features, n, p0, s)
+                if not pfirst:
+                    side.wait_event(ev_pbptt)
+                    if ws.get("ev_order") is not None:
+                        side.wait_event(ws.pop("ev_order"))
+                    self._policy_weight_grads(ws, features, n, p0, s)
                 side.wait_event(ev_vocab)
                 self._mark("side:policy_bwd_done")
                 self._ev_policy = torch.cuda.Event()
@@ -1737,21 +1863,28 @@ class A2CEngine:
             ws["X_pending"] = False
         dgp = ws["dgp"]
         dg_all = dgp.view(t_steps * n, 4 * H)
-        dg_cols = self._scale_of(ws, "pdgc", dg_all, True) if self.vgd == "f16x2" else None
+        if self.vgd == "f16x2":
+            dg_rows, dg_cols = self._scales_of(ws, "pdg", dg_all)
+            emb_cols, wih_cols = ws.get("psc_embP"), ws.get("psc_wihP")
+        else:
+            dg_rows = dg_cols = emb_cols = wih_cols = None
         self._pgemm(ws, "pih", dg_all, ws["X"].view(t_steps * n, -1), gP["lstm.weight_ih_l0"], ss, self.vgd, a_kmajor=True,
-                    b_kmajor=True, shared=True, a_scale=dg_cols)
+                    b_kmajor=True, shared=True, a_scale=dg_cols, b_scale=emb_cols)
+        # (Hbuf's first rows are h0 = cnn2linear(features), not an LSTM output: no bound, so its columns get a pass -
+        # beside the forward chains when the step has one, see _chains_forward_loss)
         self._pgemm(ws, "phh", dg_all, ws["Hbuf"][:t_steps].view(t_steps * n, H), gP["lstm.weight_hh_l0"], ss, self.vgd,
-                    a_kmajor=True, b_kmajor=True, shared=True, a_scale=dg_cols)
+                    a_kmajor=True, b_kmajor=True, shared=True, a_scale=dg_cols, b_scale=ws.get("psc_hbuf"))
         hip.colsum(dg_all, gP["lstm.bias_ih_l0"], scratch=ws["cs_side"])
         gP["lstm.bias_hh_l0"].copy_(gP["lstm.bias_ih_l0"])
         g_emb = gP.get("caption_embedding.weight")
         if g_emb is not None:
-            self._pgemm(ws, "pdx", dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, self.vgd, b_kmajor=True, shared=True)
+            self._pgemm(ws, "pdx", dg_all, P["lstm.weight_ih_l0"], ws["dX"], ss, self.vgd, b_kmajor=True, shared=True,
+                        a_scale=dg_rows, b_scale=wih_cols)
             hip.embedding_grad(g_emb, t_steps * n, ws["dX"], ws["emb_work"])
         hip.gemm_auto(ws["dh0"], features, gP["cnn2linear.weight"], ss, a_kmajor=True, b_kmajor=True, shared=True, dtype=self.pd)
         hip.colsum(ws["dh0"], gP["cnn2linear.bias"], scratch=ws["cs_side"])
 
-    def _policy_backward_beside_chain(self, ws, n, p0, s, ev_loss, side):
+    def _policy_backward_beside_chain(self, ws, n, p0, s, ev_loss, side, vocab_later=False):
         """The part of the policy network's backward pass that needs the loss but no BPTT, queued beside the value
         chain's BPTT (see _tail_ok).  Third stream: U = G0 . W (unless an earlier attempt of this minibatch has
         formed it), what flows into the LSTM outputs (coef * U), coef * Hs, then the value head's weight
@@ -1782,8 +1915,18 @@ class A2CEngine:
             # the vocabulary matrix's gradients follow on the same stream, beside the value chain's BPTT (whose
             # workgroups hold half of the CUs); on the side stream they queued behind the replay check and ran after
             # both BPTT launches, when nothing was left to run beside them
-            hip.scale_rows(Hs, coef, ws["HsC"])
-            self._vocab_weight_grad(ws, G0, ws["scratch_check"])
+            if not vocab_later:
+                hip.scale_rows(Hs, coef, ws["HsC"])
+                self._vocab_weight_grad(ws, G0, ws["scratch_check"])
+
+        def order_tokens():
+            if "order_pending" in ws:
+                n_rows = ws.pop("order_pending")
+                if any(g is not None and g.get(k) is not None for g, k in
+                       ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
+                    hip.token_order(ws["tokT"].view(-1), 1, n_rows[1], self._emb_vocab(), ws["emb_work"])
+                    ws["ev_order"] = ws["ev_order_done"] = torch.cuda.Event()
+                    ws["ev_order"].record(check)
 
         def after_policy_bptt(ev_pbptt):
             """The rest of the third stream's work, released behind the policy LSTM's BPTT launch: that launch needs
@@ -1796,18 +1939,18 @@ class A2CEngine:
             return ws.pop("ev_vocab_late")
 
         def late_check_work():
+            if vocab_later:
+                # (policy BPTT first: the token order, which the policy network's embedding gradient waits for beside
+                # the value chain's BPTT, then the vocabulary weight gradient)
+                order_tokens()
+                hip.scale_rows(Hs, coef, ws["HsC"])
+                self._vocab_weight_grad(ws, G0, ws["scratch_check"])
             hip.colsum(G0, gP["linear2vocab.bias"], scratch=ws["cs_check"], row_scale=coef)
             ev_vocab = torch.cuda.Event()
             ev_vocab.record(check)
             ws["ev_vocab_late"] = ev_vocab
             self._mark("check:vocab_grads_done")
-            if "order_pending" in ws:
-                n_rows = ws.pop("order_pending")
-                if any(g is not None and g.get(k) is not None for g, k in
-                       ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
-                    hip.token_order(ws["tokT"].view(-1), 1, n_rows[1], self._emb_vocab(), ws["emb_work"])
-                    ws["ev_order"] = ws["ev_order_done"] = torch.cuda.Event()
-                    ws["ev_order"].record(check)
+            order_tokens()
             pending = ws.pop("head_grads_pending", None)
             if pending is not None:   # the value head's weight gradients: off the path to the chain's BPTT
                 self._value_head_weight_grads(ws, *pending, ws["scratch_check"], ws["cs_check"])
