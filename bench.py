@@ -240,6 +240,8 @@ def main():
     local = local % max(1, torch.cuda.device_count())   # more ranks than GPUs (a rehearsal): they share
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if os.environ.get("ICRL_BENCH_OWN_STREAM") == "1":   # diagnosis: the step's main stream is not the device's default one
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     n, vocab, caplen, fdim = args.batch, args.vocab, args.caplen, args.fdim
     steps_per_rollout = caplen - 1
 
@@ -281,7 +283,12 @@ def main():
 
     sync_each = os.environ.get("ICRL_BENCH_SYNC_EACH") == "1"   # diagnosis: the device drained after every minibatch
 
+    head_start = int(os.environ.get("ICRL_BENCH_HEAD_START", "0"))   # diagnosis (kernel traces): the device idles this many
+    # clock ticks in front of every minibatch, so that a host slowed down by a profiler still queues ahead of it
+
     def one_step(i):
+        if head_start:
+            torch.cuda._sleep(head_start)
         res = engine.step(feats_d, prefix_d, steps_per_rollout, uniforms=uniforms[i])
         averager.finish()
         opt.step()

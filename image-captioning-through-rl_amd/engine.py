@@ -46,6 +46,7 @@ the same kernels (a "segment" is a row: no warm-up, no seams, nothing approximat
 All device memory is PyTorch-owned and cached per problem shape; nothing here touches
 the CPU oracle, and every kernel call raises if libicrl_a2c.so is missing.
 """
+import os
 import torch
 
 from . import hipabi as hip
@@ -613,7 +614,7 @@ class A2CEngine:
     def _rollout_f16x2(self):
         return self.rollout_arith == "f16x2" and self.pd == "f32" and self.E % 16 == 0
 
-    def _policy_table(self, ws):
+    def _policy_table(self, ws, stacked_on=None, after=None):
         """Per-word input side of the policy LSTM, table[w] = W_ih emb[w] + b_ih + b_hh (models.py:73, 80), and
         the vocabulary projection stacked on W_hh, so that one product gives a step's logits and the recurrent
         half of the next step's gates.  They depend on the parameters only: built beside the first rollout steps.
@@ -628,17 +629,22 @@ class A2CEngine:
             ws["Wcat"] = torch.zeros(Vp + 4 * H, H, dtype=torch.float32, device=dev)
             ws["bcat"] = torch.zeros(Vp + 4 * H, dtype=torch.float32, device=dev)
             ws["logits_ext"] = torch.empty(ws["logits"].shape[0], Vp + 4 * H, dtype=torch.float32, device=dev)
-        ws["Wcat"][:V].copy_(P["linear2vocab.weight"])
-        ws["Wcat"][Vp:].copy_(P["lstm.weight_hh_l0"])
-        ws["bcat"][:V].copy_(P["linear2vocab.bias"])
-        if self._rollout_f16x2():
-            if "Wcat_p" not in ws:
+            if self._rollout_f16x2():
                 rows = ws["logits"].shape[0]
                 ws["Wcat_p"], ws["Wcat_d"] = hip.f16x2_pieces(Vp + 4 * H, H, self.device)
                 ws["h_p"], ws["h_d"] = hip.f16x2_pieces(rows, H, self.device)
                 ws["h_d"].fill_(1.0 / 4096.0)
-            hip.cut_f16x2(ws["Wcat"], ws["Wcat_p"], ws["Wcat_d"])
-            # the rounds before the table is ready use the vocabulary rows of the pieces already
+        # the stacked weight on `stacked_on` (a stream beside the current one: both are on the path to the rollout's
+        # first round, 0.05 and 0.13 ms), the table on the current stream
+        with torch.cuda.stream(stacked_on if stacked_on is not None else torch.cuda.current_stream()):
+            if stacked_on is not None and after is not None:
+                stacked_on.wait_event(after)
+            ws["Wcat"][:V].copy_(P["linear2vocab.weight"])
+            ws["Wcat"][Vp:].copy_(P["lstm.weight_hh_l0"])
+            ws["bcat"][:V].copy_(P["linear2vocab.bias"])
+            if self._rollout_f16x2():
+                hip.cut_f16x2(ws["Wcat"], ws["Wcat_p"], ws["Wcat_d"])
+            # (the rounds before the table is ready use the vocabulary rows of the pieces already)
             ws["ev_wcat"] = torch.cuda.Event()
             ws["ev_wcat"].record(torch.cuda.current_stream())
         if self._rollout_f16x2():
@@ -703,6 +709,7 @@ class A2CEngine:
             if ev_table is not None and self.NEXT_CELL_FROM <= k + 1 < t_steps:
                 if ev_table is not True:
                     torch.cuda.current_stream().wait_event(ev_table)
+                    torch.cuda.current_stream().wait_event(ws["ev_wcat"])
                     ev_table = True
                 ext = ws["logits_ext"][:n]
                 if self._rollout_f16x2():
@@ -715,7 +722,8 @@ class A2CEngine:
                         # device takes launches up in about the order the host queues them, so work queued before the
                         # rollout delays its first round and work queued after all of it starts when it ends)
                         total = t_steps - 1 - k
-                        for rounds in ((min(2, total), total - min(2, total)) if between is not None else (total,)):
+                        splits = (min(2, total), total - min(2, total)) if between is not None else (total,)
+                        for rounds in splits:
                             if rounds > 0:
                                 hip.policy_rollout_rounds(
                                     ws["Wcat_p"], ws["Wcat_d"], ws["bcat"], ws["h_p"], ws["h_d"], ext, n, V, self._padded_vocab(),
@@ -1015,7 +1023,8 @@ class A2CEngine:
         with torch.cuda.stream(tables_on):
             tables_on.wait_event(ev_start)
             if self._policy_table_wanted(n, p0, s, mode):
-                self._policy_table(ws)
+                self._policy_table(ws, stacked_on=side if self.concurrent else None,
+                                   after=ev_start)
                 ev_table_p = torch.cuda.Event()
                 ev_table_p.record(tables_on)
         events = {}
@@ -1256,7 +1265,7 @@ class A2CEngine:
     def _uvocab(self, ws, G0, scratch):
         """ws["Uvocab"] = G0 . linear2vocab.weight on the current stream (what flows into the LSTM outputs, up to the
         per-row coefficient)."""
-        rows = self._g0_scales(ws, G0, False)[0] if self.vgd == "f16x2" else None
+        rows = self._g0_row_scales(ws, G0) if self.vgd == "f16x2" else None
         self._pgemm(ws, "uvoc", G0, self.P["linear2vocab.weight"], ws["Uvocab"], scratch, self.vgd, b_kmajor=True, shared=True,
                     a_scale=rows, b_scale=ws.get("psc_wvoc") if self.vgd == "f16x2" else None)
 
@@ -1264,7 +1273,7 @@ class A2CEngine:
         """linear2vocab.weight's gradient G0^T . (coef * Hs) on the current stream."""
         colsc = None
         if self.vgd == "f16x2":
-            _, colsc, ev = self._g0_scales(ws, G0, True)
+            colsc, ev = self._g0_col_scales(ws, G0)
             torch.cuda.current_stream().wait_event(ev)   # (they may have been computed on another stream, beside the chains)
         self._pgemm(ws, "gvoc", G0, ws["HsC"], self.gP["linear2vocab.weight"], scratch, self.vgd, a_kmajor=True, b_kmajor=True,
                     shared=True, a_scale=colsc)
@@ -1421,6 +1430,10 @@ class A2CEngine:
                 self._reward_head(ws, features, n, s, side, visual_done=True)
                 ev_rew = torch.cuda.Event()
                 ev_rew.record(side)
+                if backward and self.vgd == "f16x2" and ws.get("defer_replay"):
+                    # the side stream is idle from here to the end of the policy LSTM's BPTT: the pass over G0 for its
+                    # column scales (the vocabulary weight gradient's), beside G0 . W on the third stream
+                    self._g0_col_scales(ws, ws["dlogits"].view(s * n, self.vocab))
         elif seg:
             hip.lstm_chain_fwd_seg(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, plan[1], plan[2], ws["hv"],
                                    ws["saved"] if keep else None, ws["work_v"], ws["seam"][0:2], full_calls=fc)
@@ -1434,9 +1447,10 @@ class A2CEngine:
             replay_steps = min((p0 + fc - 1) * n, self._replay_steps(max(plan[2], plan_r[2])))
             ev_chains = torch.cuda.Event()
             ev_chains.record(main)
-            check = self._replay_stream() if self.concurrent else main
+            replay_on = self._replay_stream() if self.concurrent else main
 
             def launch_replay(after=None):
+                check = replay_on
                 with torch.cuda.stream(check):
                     check.wait_event(ev_chains)
                     if after is not None:
@@ -1582,21 +1596,26 @@ class A2CEngine:
         hip.gemm_auto(a, b, out, scratch, a_kmajor=a_kmajor, b_kmajor=b_kmajor, shared=shared, dtype=dtype, a_scale=a_scale,
                       b_scale=b_scale)
 
-    def _g0_scales(self, ws, G0, want_cols):
-        """Scales of G0 = onehot(token) - softmax for the two-piece products, on the current stream: per row from the
-        rows' log-probabilities (hipabi.g0_row_scales), per column (one pass over the matrix) when asked for.
-        Computed once per rollout; returns (row scales, column scales or None, event after which they are complete)."""
-        got = ws.get("g0_scales")
-        if got is None or got[0] != ws["rollout_id"] or (want_cols and got[2] is None):
-            rows = ws.get("g0_row_scale")
-            if rows is None or rows.numel() < G0.shape[0]:
-                rows = ws["g0_row_scale"] = torch.empty(G0.shape[0], dtype=torch.float32, device=self.device)
-            hip.g0_row_scales(ws["logp"].view(-1)[:G0.shape[0]], rows)
-            colsc = self._scale_of(ws, "g0c", G0, True) if want_cols else None
+    def _g0_row_scales(self, ws, G0):
+        """Row scales of G0 = onehot(token) - softmax for the two-piece products, on the current stream, from the rows'
+        log-probabilities (the largest magnitude of a row is 1 - p_token: hipabi.g0_row_scales)."""
+        rows = ws.get("g0_row_scale")
+        if rows is None or rows.numel() < G0.shape[0]:
+            rows = ws["g0_row_scale"] = torch.empty(G0.shape[0], dtype=torch.float32, device=self.device)
+        hip.g0_row_scales(ws["logp"].view(-1)[:G0.shape[0]], rows)
+        return rows
+
+    def _g0_col_scales(self, ws, G0):
+        """Column scales of G0 (one pass over the matrix, 0.4 GB at the metric's size) on the current stream, once per
+        rollout: returns (scales, the event after which they are complete).  Bound by memory traffic, so it is queued
+        where it runs beside a product bound by the matrix instruction (_chains_forward_loss), not in the step's tail."""
+        got = ws.get("g0_col_scales")
+        if got is None or got[0] != ws["rollout_id"]:
+            colsc = self._scale_of(ws, "g0c", G0, True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            got = ws["g0_scales"] = (ws["rollout_id"], rows, colsc, ev)
-        return got[1], got[2], got[3]
+            got = ws["g0_col_scales"] = (ws["rollout_id"], colsc, ev)
+        return got[1], got[2]
 
     def _value_head_weight_grads(self, ws, features, n, s, scratch, cs):
         """Weight and bias gradients of the value head's two linear layers, from ws["dvalue"] and ws["dY"], on the
@@ -1687,12 +1706,11 @@ class A2CEngine:
                 ws["ev_ctl"].record(main)
 
         if pfirst:
-            # In the order the device is to take them up (it dispatches roughly in the order of submission, and a
-            # launch that is ready but finds no room holds back what was submitted after it, on any stream): the
-            # read-back, the replay check (64 half-CU workgroups: they fit beside the BPTT's 128 CUs only while the
-            # products have not filled the rest), the policy network's weight gradients, the vocabulary weight
-            # gradient and the third stream's small launches; the value network's weight gradients follow on the main
-            # stream.
+            # The read-back first, then the replay check on the side stream in front of the policy network's weight
+            # gradients (64 half-CU workgroups: they fit beside the BPTT's 128 CUs only while the products have not
+            # filled the rest; and the host waits for its result before it accepts the forward pass - queued behind the
+            # products, on either stream, the step took 5.85 ms against 5.2), the vocabulary weight gradient and the
+            # third stream's small launches; the value network's weight gradients follow on the main stream.
             read_back()
             if "replay_deferred" in ws:
                 ws["ev_replay_late"] = ws.pop("replay_deferred")(ev_pbptt)
