@@ -46,7 +46,6 @@ the same kernels (a "segment" is a row: no warm-up, no seams, nothing approximat
 All device memory is PyTorch-owned and cached per problem shape; nothing here touches
 the CPU oracle, and every kernel call raises if libicrl_a2c.so is missing.
 """
-import os
 import torch
 
 from . import hipabi as hip
@@ -250,6 +249,7 @@ class A2CEngine:
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
         self._replay_need, self._replay_cool, self._replay_penalty = 0, 0, 32
         self.last_replay = None      # (full_calls, steps, err value chain, err reward chain) of the last step
+        self._policy_give_ups = 0    # minibatches in a row whose one-launch policy BPTT gave up
         self.launch_timeouts = 0     # attempts repeated because a persistent launch gave up waiting for a workgroup
         self._check = None           # third stream: loss-independent policy backward, vocabulary gradients
         self._replay = None          # fourth stream (if one overlaps the others): the replay check
@@ -495,6 +495,10 @@ class A2CEngine:
         if fc < s and not self.segments:
             k = min(k, self.COLLAPSED_MAX_SEGMENTS)
         plan = lambda i: ("segmented", k, self.warmups[i]) if i < last else ("exact",)
+        # (Measured and dropped: half as many segments for the forward pair once its warm-up is long.  Alone the launch
+        # gains - a step costs 4.8 us with one workgroup per CU against 5.9 with two: warm-up 256, 1.62 against 1.73 ms -
+        # but with one workgroup per CU the products queued behind it run beside it, and the step loses: 7.31-7.41
+        # against 7.25 ms at steady state.)
         return fc, plan(fv), plan(fr), plan(bi)
 
     def _bwd_f16x2(self, rows):
@@ -1145,10 +1149,6 @@ class A2CEngine:
                 if with_bwd and pb[0] == "exact":
                     self._ladder_bwd.accepted(bi, [], last)
             self.last_seam = ws["seam_host"].tolist()[:4] + [0.0, 0.0]
-            if with_bwd and self.on_policy_grads is not None and self._ev_policy is not None:
-                # the forward pass stands, so the policy gradients being computed now are final
-                self.on_policy_grads(self._ev_policy)
-                self._ev_policy = None
             # ---- the backward seam
             restart = False
             while with_bwd and pb[0] == "segmented":
@@ -1189,6 +1189,30 @@ class A2CEngine:
                 self._mark("backward_done")
             if restart:
                 continue
+            if with_bwd and tail and status_host is not None and status_host[3] != 0 and gave_up <= self.MAX_GIVE_UPS:
+                # the policy LSTM's one-launch BPTT gave up waiting for its workgroups (it needs every CU; another
+                # process on the GPU held some): once more with a launch per step, which waits for nobody, and its
+                # weight gradients again (everything else of the minibatch stands)
+                gave_up += 1
+                self.launch_timeouts += 1
+                self._redo_policy_bptt(ws, features, n, p0, s, main)
+                status_host[3] = 0
+                self._policy_give_ups += 1
+                if self._policy_give_ups == self.MAX_GIVE_UPS and self.late_policy_bptt:
+                    # three minibatches in a row: something keeps the device from holding the launch (each give-up
+                    # costs its 20 ms wait): the policy LSTM's BPTT goes back to a launch per step from here on
+                    import warnings
+                    warnings.warn("the policy LSTM's one-launch BPTT gave up waiting for its workgroups in %d minibatches in "
+                                  "a row: this engine goes on with one launch per step for it" % self.MAX_GIVE_UPS,
+                                  RuntimeWarning)
+                    self.late_policy_bptt = False
+            elif with_bwd and tail:
+                self._policy_give_ups = 0
+            if with_bwd and self.on_policy_grads is not None and self._ev_policy is not None:
+                # the forward pass stands and no launch of the backward pass is repeated any more, so the policy
+                # gradients being computed now are final
+                self.on_policy_grads(self._ev_policy)
+                self._ev_policy = None
             break
         self._replay_accepted()
         self._warm16_off = max(0, self._warm16_off - 1)
@@ -1199,6 +1223,7 @@ class A2CEngine:
         return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pv, pb), pr, status_host, full_calls=fc)
 
+    LONG_REPLAY = 160   # steps of a replay check from which the side stream is left to it alone (see _value_chain_backward)
     MAX_GIVE_UPS = 3   # attempts of one minibatch whose persistent launch may give up before the engine stops using them
 
     def _degrade_to_per_step_launches(self):
@@ -1441,10 +1466,12 @@ class A2CEngine:
             hip.lstm_chain_fwd(ws["XPv"], V["valrnn.lstm.weight_hh_l0"], n, p0, s, ws["hv"],
                                ws["saved"] if backward else None, ws["sync_v"], ws["status"][0:1])
         ev_replay, replay_steps = None, 0
+        ws["replay_steps"] = 0
         if collapsed:
             # beside everything that follows, on a stream of its own: the first steps of every replay that was
             # left out, from the state the chain had there
             replay_steps = min((p0 + fc - 1) * n, self._replay_steps(max(plan[2], plan_r[2])))
+            ws["replay_steps"] = replay_steps
             ev_chains = torch.cuda.Event()
             ev_chains.record(main)
             replay_on = self._replay_stream() if self.concurrent else main
@@ -1669,7 +1696,7 @@ class A2CEngine:
                                    ws["sync_v"], ws["status"][2:3])
 
         pfirst = tail and self.policy_bptt_first
-        ev_dhall = rest_of_third_stream = ev_pbptt = ev_vocab = None
+        ev_dhall = rest_of_third_stream = ev_pbptt = ev_vocab = ev_pw = None
 
         def policy_bptt():
             # the policy LSTM's backward-through-time: one persistent launch
@@ -1712,19 +1739,36 @@ class A2CEngine:
             # products, on either stream, the step took 5.85 ms against 5.2), the vocabulary weight gradient and the
             # third stream's small launches; the value network's weight gradients follow on the main stream.
             read_back()
+            long_replay = self.concurrent and ws.get("replay_steps", 0) >= self.LONG_REPLAY and "replay_deferred" in ws
             if "replay_deferred" in ws:
                 ws["ev_replay_late"] = ws.pop("replay_deferred")(ev_pbptt)
-            with torch.cuda.stream(side):
-                side.wait_event(ev_pbptt)
-                if "order_pending" in ws:
-                    n_rows = ws.pop("order_pending")
-                    if any(g is not None and g.get(k) is not None for g, k in
-                           ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
-                        hip.token_order(ws["tokT"].view(-1), 1, n_rows[1], self._emb_vocab(), ws["emb_work"])
-                        ws["ev_order_done"] = torch.cuda.Event()
-                        ws["ev_order_done"].record(side)
-                self._policy_weight_grads(ws, features, n, p0, s)
+            # The policy network's weight gradients: on the side stream behind the replay check - or, when that check
+            # is long (it walks as many steps as the warm-ups, 2 ms once the value LSTM's memory has grown, and would
+            # hold them back until the BPTT beside which they should run is over), on the third stream behind the
+            # vocabulary weight gradient
+            ev_pw = None
+            wgrads_on = self._check_stream() if long_replay else side
+
+            def policy_weight_grads():
+                with torch.cuda.stream(wgrads_on):
+                    wgrads_on.wait_event(ev_pbptt)
+                    if "order_pending" in ws:
+                        n_rows = ws.pop("order_pending")
+                        if any(g is not None and g.get(k) is not None for g, k in
+                               ((self.gP, "caption_embedding.weight"), (self.gV, "valrnn.caption_embedding.weight"))):
+                            hip.token_order(ws["tokT"].view(-1), 1, n_rows[1], self._emb_vocab(), ws["emb_work"])
+                            ws["ev_order_done"] = torch.cuda.Event()
+                            ws["ev_order_done"].record(wgrads_on)
+                    self._policy_weight_grads(ws, features, n, p0, s)
+                    ev = torch.cuda.Event()
+                    ev.record(wgrads_on)
+                return ev
+
+            if not long_replay:
+                ev_pw = policy_weight_grads()
             ev_vocab = rest_of_third_stream(ev_pbptt)
+            if long_replay:
+                ev_pw = policy_weight_grads()
         elif tail:
             # queued BEHIND the chain's launch although it waits for the loss only: launches that the host queues
             # first get the device first, and with two vocabulary-sized products (36 KB of LDS per workgroup, four
@@ -1813,6 +1857,8 @@ class A2CEngine:
                     if ws.get("ev_order") is not None:
                         side.wait_event(ws.pop("ev_order"))
                     self._policy_weight_grads(ws, features, n, p0, s)
+                elif ev_pw is not None:
+                    side.wait_event(ev_pw)
                 side.wait_event(ev_vocab)
                 self._mark("side:policy_bwd_done")
                 self._ev_policy = torch.cuda.Event()
@@ -1868,6 +1914,17 @@ class A2CEngine:
                              ws["dh0"], ss, shared=True, dtype=self.pd)
         self._policy_weight_grads(ws, features, n, p0, s)
         cur.wait_event(ev_vocab)
+
+    def _redo_policy_bptt(self, ws, features, n, p0, s, main):
+        """The policy LSTM's backward-through-time with one launch per step and what follows it, on the main stream
+        behind everything the minibatch has queued: for a minibatch whose one-launch BPTT gave up (ws["dHall"], the
+        kept gates and cell states are as that launch found them)."""
+        ws["status"][3:4].zero_()
+        hip.policy_lstm_bptt(ws["gates"], ws["Cbuf"], ws["dHall"], self.P["lstm.weight_hh_l0"], ws["dgp"], ws["dc0"],
+                             ws["dc1"], ws["dh0"], ws["scratch_side"], shared=True, dtype=self.pd)
+        self._policy_weight_grads(ws, features, n, p0, s)
+        self._ev_policy = torch.cuda.Event()
+        self._ev_policy.record(main)
 
     def _policy_weight_grads(self, ws, features, n, p0, s):
         """What follows the policy LSTM's BPTT, on the current stream: the gradients of its weights, biases and

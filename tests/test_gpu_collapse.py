@@ -247,3 +247,29 @@ def test_long_memory_is_caught_by_the_replay_check():
         engine.SEAM_TOL_FWD = float("inf")
     eng, res, _ = _step(a2c, rew, feats, caps, 1, 7, u, before=seams_never_object)
     assert eng.fallbacks >= 1 and res.full_calls > 1
+
+
+def test_policy_bptt_launch_that_gave_up_is_walked_again_step_by_step(monkeypatch):
+    """The policy LSTM's one-launch BPTT needs every CU; when it gives up waiting for its workgroups (another process
+    holds some) it leaves its status word set and its outputs unfinished.  Simulated here: the launch runs, then its
+    gate gradients are overwritten with NaN and the status word is set.  The step must notice at the backward seam
+    read-back, walk the BPTT again with a launch per step, form the policy network's weight gradients again, count
+    the give-up, and end on the gradients of the exact kernels."""
+    cfg = dict(n=256, vocab=300, caplen=9, fdim=512, seed=37, level=None)
+    a2c, rew = _modules(cfg)
+    feats, caps = synthetic.make_minibatch(256, 300, 9, 512, 37)
+    u = synthetic.make_uniforms(37, 8 * 256)
+    _, exact, g_exact = _step(a2c, rew, feats, caps, 1, 8, u, chain_mode="exact", collapse_replays=False)
+    real, calls = hip.policy_lstm_bptt_persist, []
+
+    def gives_up(gates, c, dh_all, w_hh, dgp, dh0, work, status, **kw):
+        real(gates, c, dh_all, w_hh, dgp, dh0, work, status, **kw)
+        dgp.fill_(float("nan"))
+        dh0.fill_(float("nan"))
+        status.fill_(1)
+        calls.append(1)
+    monkeypatch.setattr(hip, "policy_lstm_bptt_persist", gives_up)
+    eng, res, grads = _step(a2c, rew, feats, caps, 1, 8, u)
+    assert len(calls) == 1, "the step took the one-launch BPTT (else this test checks nothing)"
+    assert eng.launch_timeouts == 1 and res.status_host[3] == 0
+    _same_step(res, grads, exact, g_exact)
