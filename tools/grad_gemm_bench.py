@@ -1,12 +1,14 @@
 """The backward pass's product shapes on two scaled f16 pieces (dtype "f16x2") and on three bf16 pieces ("f32x3"), with the
 passes that compute the scales, each alone on the device (10 launches, HIP events).
 
-    python tools/grad_gemm_bench.py
+    python tools/grad_gemm_bench.py [path of another build of libicrl_a2c.so]
 """
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 hip = importlib.import_module(bench.PKG + ".hipabi")
+if len(sys.argv) > 1:   # another build of the library (kernel variants under test)
+    hip.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device("cuda", 0)
 def run(m, n, k, akm, bkm):
     a = torch.randn((k, m) if akm else (m, k), device=dev); b = torch.randn((k, n) if bkm else (n, k), device=dev)
