@@ -277,9 +277,14 @@ def main():
     uniforms = torch.from_numpy(
         np.random.RandomState(1000 + rank).random_sample((total_steps, steps_per_rollout * n))).to(dev)
 
-    # N > 1: the policy network's gradients cross the links beside the value chain's backward pass
+    # N > 1: one all-reduce of the flat gradient buffer at the end of the minibatch.  (With the value chain's BPTT in
+    # front of the policy LSTM's - the earlier schedule, --value-bptt-first - the policy network's gradients are
+    # complete milliseconds before the value network's and cross the links in a piece of their own beside the rest of
+    # the backward pass; with the policy BPTT first both are complete at about the same time, and two more collectives
+    # would only add their launches.  The choice is a constructor-level one, so every rank takes it alike.)
     averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."), stream=engine.side_stream())
-    engine.on_policy_grads = averager.start_early
+    if not engine.policy_bptt_first:
+        engine.on_policy_grads = averager.start_early
 
     sync_each = os.environ.get("ICRL_BENCH_SYNC_EACH") == "1"   # diagnosis: the device drained after every minibatch
 

@@ -221,13 +221,15 @@ def _a2c_minibatch(engine, optimizer, captions, features, p0, n_steps):
     flat = getattr(optimizer, "fp", None)
     averager = None
     if flat is not None and ddp.world_size() > 1:
-        # the policy network's gradients are complete well before the value network's: their all-reduce
-        # starts as soon as the engine says so and runs beside the value chain's backward pass
+        # one all-reduce of the flat buffer after the step - or, with the value chain's BPTT queued in front of the
+        # policy LSTM's (policy_bptt_first=False), where the policy network's gradients are complete well before the
+        # value network's, their all-reduce started as soon as the engine says so, beside the rest of the backward
+        # pass.  (The switch is a constructor argument, the same on every rank: every rank issues the same collectives.)
         averager = getattr(engine, "_averager", None)
         if averager is None or averager.flat_grad is not flat.flat_grad:
             averager = engine._averager = ddp.GradientAverager(flat.flat_grad, flat.span("policy_network."),
                                                                stream=engine.side_stream())
-        engine.on_policy_grads = averager.start_early
+        engine.on_policy_grads = None if engine.policy_bptt_first else averager.start_early
     res = engine.step(feats, prefix, n_steps, uniforms=uniforms)
     if averager is not None:
         averager.finish()
