@@ -76,17 +76,17 @@ __device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned&
 // of them 64 consecutive rows per wave, stored as three 16-byte pieces (eight lanes of a store hit eight different
 // bank groups; a thread that owned four rows of one k, as float4 loads along the rows would have it, puts the
 // lanes of a store four rows apart, which with rows a multiple of 16 bytes apart is two banks for all of them).
-template <int ROWS, bool KM>
+template <int ROWS, bool KM, int NTH = NT>
 struct Stage {
-    static constexpr int PIECES = KM ? ROWS * BK / 8 / NT : ROWS * BK / 4 / NT;
-    static_assert(PIECES >= 1 && PIECES * NT * (KM ? 8 : 4) == ROWS * BK, "the tile divides among the threads");
+    static constexpr int PIECES = KM ? ROWS * BK / 8 / NTH : ROWS * BK / 4 / NTH;
+    static_assert(PIECES >= 1 && PIECES * NTH * (KM ? 8 : 4) == ROWS * BK, "the tile divides among the threads");
     float x[PIECES][KM ? 8 : 4];
     float sc[PIECES];   // NP = 2: the power-of-two scale of each piece's row (a piece's row is the same in every stage)
 
     __device__ __forceinline__ void scales(const float* s, int row0, int nrows, int tid) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int f = tid + NT * i;
+            const int f = tid + NTH * i;
             sc[i] = s[min(row0 + (KM ? f % ROWS : f / (BK / 4)), nrows - 1)];
         }
     }
@@ -98,7 +98,7 @@ struct Stage {
     __device__ __forceinline__ void load(const float* base, int64_t ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int f = tid + NT * i;
+            const int f = tid + NTH * i;
             if (!KM) {
                 const int gr = EDGE ? row0 + f / (BK / 4) : min(row0 + f / (BK / 4), nrows - 1), gk = k0 + 4 * (f % (BK / 4));
                 const float* p = base + (int64_t)gr * ld + gk;
@@ -122,7 +122,7 @@ struct Stage {
     __device__ __forceinline__ void store(lds_t* lds, int plane, int tid) const {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int f = tid + NT * i;
+            const int f = tid + NTH * i;
             if (!KM) {
                 uint2 w[3];
                 if (NP == 3) {
@@ -170,15 +170,16 @@ struct GemmArgs {
     const float* sb;
 };
 
-template <int NP, bool A_KM, bool B_KM, bool EDGE>
-__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], lds_t* lds, int m0, int n0, int kbeg,
+template <int NP, bool A_KM, bool B_KM, bool EDGE, int BM_ = BM, int BN_ = BN, int NTH = NT, int WI = 2, int WJ = 2>
+__device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[WI][WJ], lds_t* lds, int m0, int n0, int kbeg,
                                        int kend, int nk, int tid) {
-    constexpr int DEPTH = 4;   // stages in flight in registers
+    constexpr int DEPTH = BM_ * BN_ > BM * BN ? 2 : 4;   // stages in flight in registers (the large tile has the accumulators of four)
+    constexpr int A_PL = BM_ * LDK, B_PL = BN_ * LDK;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / (BN_ / (32 * WJ)), wc = wave % (BN_ / (32 * WJ));
     const int l31 = lane & 31, h = lane >> 5;
-    Stage<BM, A_KM> sa[DEPTH];
-    Stage<BN, B_KM> sb[DEPTH];
+    Stage<BM_, A_KM, NTH> sa[DEPTH];
+    Stage<BN_, B_KM, NTH> sb[DEPTH];
     if (NP == 2) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -201,10 +202,10 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], l
             const int kt = kt0 + d;
             if (kt < nk) {
                 const lds_t* la = lds;
-                const lds_t* lb = la + NP * A_PLANE;
+                const lds_t* lb = la + NP * A_PL;
                 if (kt > 0) __syncthreads();
-                sa[d].template store<NP>(lds, A_PLANE, tid);
-                sb[d].template store<NP>(lds + NP * A_PLANE, B_PLANE, tid);
+                sa[d].template store<NP>(lds, A_PL, tid);
+                sb[d].template store<NP>(lds + NP * A_PL, B_PL, tid);
                 if (kt + DEPTH < nk) {
                     sa[d].template load<EDGE>(g.A, g.lda, m0, g.M, kbeg + (kt + DEPTH) * BK, kend, tid);
                     sb[d].template load<EDGE>(g.B, g.ldb, n0, g.N, kbeg + (kt + DEPTH) * BK, kend, tid);
@@ -212,17 +213,17 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], l
                 __syncthreads();
 #pragma unroll
                 for (int ks = 0; ks < BK / 16; ++ks) {
-                    u32x4 av[2][NP], bv[2][NP];
+                    u32x4 av[WI][NP], bv[WJ][NP];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            av[i][p] = frag(la + p * A_PLANE, wr * 64 + i * 32 + l31, ks, h);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int i = 0; i < WI; ++i)
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
-                            bv[j][p] = frag(lb + p * B_PLANE, wc * 64 + j * 32 + l31, ks, h);
+                            av[i][p] = frag(la + p * A_PL, wr * (32 * WI) + i * 32 + l31, ks, h);
+#pragma unroll
+                    for (int j = 0; j < WJ; ++j)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            bv[j][p] = frag(lb + p * B_PL, wc * (32 * WJ) + j * 32 + l31, ks, h);
                     // piece products, smallest first: (a piece, b piece) with piece 0 = hi, 1 = mid, 2 = lo
                     constexpr int NQ = NP == 3 ? 6 : 3;
                     constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
@@ -230,9 +231,9 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], l
 #pragma unroll
                     for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < WI; ++i)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) {
+                            for (int j = 0; j < WJ; ++j) {
                                 if (NP == 3)
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                         __builtin_bit_cast(bf16x8, av[i][PA[q]]), __builtin_bit_cast(bf16x8, bv[j][PB[q]]), acc[i][j], 0, 0, 0);
@@ -246,18 +247,18 @@ __device__ __forceinline__ void k_loop(const GemmArgs& g, f32x16 (&acc)[2][2], l
     }
 }
 
-template <int NP, bool A_KM, bool B_KM>
+template <int NP, bool A_KM, bool B_KM, int BM_ = BM, int BN_ = BN, int NTH = NT, int WI = 2, int WJ = 2>
 __device__ __forceinline__ void gemm_pieces(const GemmArgs& g, lds_t* lds) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / (BN_ / (32 * WJ)), wc = wave % (BN_ / (32 * WJ));
     const int l31 = lane & 31, h = lane >> 5;
 
     // XCD-aware tile order (as in gemm_f32.hip): workgroup b runs on XCD b % 8; every XCD gets one contiguous run of
     // (split, tile); tiles are walked in bands of 8 along the dimension of the larger operand, in 8 x 8 blocks.
     constexpr int BAND = 8;
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (g.M + BM_ - 1) / BM_, tiles_n = (g.N + BN_ - 1) / BN_;
     const int tiles = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {
@@ -279,13 +280,13 @@ __device__ __forceinline__ void gemm_pieces(const GemmArgs& g, lds_t* lds) {
         mt = m_fast ? f : sl;
         nt = m_fast ? sl : f;
     }
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BM_, n0 = nt * BN_;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WI][WJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -299,27 +300,27 @@ __device__ __forceinline__ void gemm_pieces(const GemmArgs& g, lds_t* lds) {
     const bool interior = aligned;   // (ragged tile rows and columns included: Stage::load)
     const int full = (kend - kbeg) / BK;
     if (interior && full > 0) {
-        k_loop<NP, A_KM, B_KM, false>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
+        k_loop<NP, A_KM, B_KM, false, BM_, BN_, NTH, WI, WJ>(g, acc, lds, m0, n0, kbeg, kbeg + full * BK, full, tid);
         if (full < nk) {
             __syncthreads();
-            k_loop<NP, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
+            k_loop<NP, A_KM, B_KM, true, BM_, BN_, NTH, WI, WJ>(g, acc, lds, m0, n0, kbeg + full * BK, kend, nk - full, tid);
         }
     } else if (nk > 0) {
-        k_loop<NP, A_KM, B_KM, true>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
+        k_loop<NP, A_KM, B_KM, true, BM_, BN_, NTH, WI, WJ>(g, acc, lds, m0, n0, kbeg, kend, nk, tid);
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + l31;
+        for (int j = 0; j < WJ; ++j) {
+            const int col = n0 + wc * (32 * WJ) + j * 32 + l31;
             if (col >= g.N) continue;
             const float badd = (g.bias && split == 0) ? g.bias[col] : 0.f;
             const float db = NP == 2 ? 1.f / g.sb[col] : 1.f;   // (powers of two: exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + wr * (32 * WI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < g.M) {
                     float* dst = Cout + (int64_t)row * g.ldc + col;
                     float v = (NP == 2 ? acc[i][j][r] * (1.f / g.sa[row]) * db : acc[i][j][r]) + badd;
@@ -342,8 +343,24 @@ __global__ __launch_bounds__(NT) void gemm_f16x2s_kernel(GemmArgs g) {
     gemm_pieces<2, A_KM, B_KM>(g, lds);
 }
 
+// The same on 256 x 256 tiles: 512 threads, a wave per 128 x 64 (four by two 32 x 32 blocks), one workgroup per CU.
+// Per element product half the operand bytes from L2, half the cutting and three quarters of the fragment reads of the
+// 128 x 128 tile.
+constexpr int BMB = 256, BNB = 256, NTB = 512;
 template <bool A_KM, bool B_KM>
-int launch_one(const GemmArgs& g, int splits, hipStream_t st) {
+__global__ __launch_bounds__(NTB) void gemm_f16x2s_big_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) lds_t lds[2 * (BMB + BNB) * LDK];
+    gemm_pieces<2, A_KM, B_KM, BMB, BNB, NTB, 4, 2>(g, lds);
+}
+
+template <bool A_KM, bool B_KM>
+int launch_one(const GemmArgs& g, int splits, hipStream_t st, bool big = false) {
+    if (big) {
+        const dim3 grid(((g.M + BMB - 1) / BMB) * ((g.N + BNB - 1) / BNB) * splits);
+        hipLaunchKernelGGL((gemm_f16x2s_big_kernel<A_KM, B_KM>), grid, dim3(NTB), 0, st, g);
+        ICRL_LAUNCH_CHECK();
+        return ICRL_OK;
+    }
     const dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * splits);
     if (g.sa) hipLaunchKernelGGL((gemm_f16x2s_kernel<A_KM, B_KM>), grid, dim3(NT), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32x3_kernel<A_KM, B_KM>), grid, dim3(NT), 0, st, g);
@@ -354,7 +371,7 @@ int launch_one(const GemmArgs& g, int splits, hipStream_t st) {
 int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor, float* C,
              int64_t ldc, int M, int N, int K, const float* bias, int accumulate, int splits, int64_t slab, int tile,
              hipStream_t st, const char* who, const float* sa = nullptr, const float* sb = nullptr) {
-    ICRL_REQUIRE(tile == 0 || tile == 1, "%s: tile must be 0 or 1 (128x128)", who);
+    ICRL_REQUIRE(tile == 0 || tile == 1 || (tile == 2 && sa), "%s: tile must be 0 or 1 (128x128), or 2 (256x256, two f16 pieces only)", who);
     ICRL_REQUIRE(A && B && C, "%s: null operand", who);
     ICRL_REQUIRE(M > 0 && N > 0 && K > 0, "%s: empty shape %dx%dx%d", who, M, N, K);
     ICRL_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N,
@@ -367,10 +384,11 @@ int dispatch(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t 
     g.kchunk = ((ksteps + splits - 1) / splits) * BK;
     g.slab = slab;
     g.sa = sa; g.sb = sb;
-    if (!a_kmajor && !b_kmajor) return launch_one<false, false>(g, splits, st);
-    if (!a_kmajor && b_kmajor) return launch_one<false, true>(g, splits, st);
-    if (a_kmajor && !b_kmajor) return launch_one<true, false>(g, splits, st);
-    return launch_one<true, true>(g, splits, st);
+    const bool big = sa && tile == 2;
+    if (!a_kmajor && !b_kmajor) return launch_one<false, false>(g, splits, st, big);
+    if (!a_kmajor && b_kmajor) return launch_one<false, true>(g, splits, st, big);
+    if (a_kmajor && !b_kmajor) return launch_one<true, false>(g, splits, st, big);
+    return launch_one<true, true>(g, splits, st, big);
 }
 
 }  // namespace
@@ -407,4 +425,14 @@ extern "C" int icrl_gemm_f16x2s_splitk(const float* A, int64_t lda, int a_kmajor
     ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f16x2s_splitk: slabs overlap");
     return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, 0, splits, slab_stride, 0,
                     icrl::as_stream(stream), "icrl_gemm_f16x2s_splitk", a_scale, b_scale);
+}
+
+extern "C" int icrl_gemm_f16x2s_splitk_tile(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B,
+                                            int64_t ldb, int b_kmajor, const float* b_scale, float* C_slabs, int64_t ldc,
+                                            int64_t slab_stride, int M, int N, int K, int splits, int tile,
+                                            icrl_stream_t stream) {
+    ICRL_REQUIRE(a_scale && b_scale, "icrl_gemm_f16x2s_splitk_tile: null scale vector");
+    ICRL_REQUIRE(slab_stride >= (int64_t)(M - 1) * ldc + N, "icrl_gemm_f16x2s_splitk_tile: slabs overlap");
+    return dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, C_slabs, ldc, M, N, K, nullptr, 0, splits, slab_stride, tile,
+                    icrl::as_stream(stream), "icrl_gemm_f16x2s_splitk_tile", a_scale, b_scale);
 }

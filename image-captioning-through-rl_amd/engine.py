@@ -1223,6 +1223,11 @@ class A2CEngine:
         return A2CStepResult(*out, ws["scalars"], ws["entropy"] if self.want_entropy else None, ws["status"],
                              (pv, pb), pr, status_host, full_calls=fc)
 
+    # the backward pass's two vocabulary-sized products on 256 x 256 tiles (alone 433 against 481 us for G0 . W and 369
+    # against 472 for G0^T . Hs; inside the step 5.09-5.11 against 5.19-5.25 ms with both, 5.12-5.14 with the second
+    # alone; the weight-gradient shapes, whose outputs are 16 such tiles, gain nothing, the input-gradient shapes
+    # 13 % alone and nothing inside the step)
+    BIG = "ug"   # ("u": G0 . W, "g": G0^T . Hs)
     LONG_REPLAY = 160   # steps of a replay check from which the side stream is left to it alone (see _value_chain_backward)
     MAX_GIVE_UPS = 3   # attempts of one minibatch whose persistent launch may give up before the engine stops using them
 
@@ -1292,7 +1297,7 @@ class A2CEngine:
         per-row coefficient)."""
         rows = self._g0_row_scales(ws, G0) if self.vgd == "f16x2" else None
         self._pgemm(ws, "uvoc", G0, self.P["linear2vocab.weight"], ws["Uvocab"], scratch, self.vgd, b_kmajor=True, shared=True,
-                    a_scale=rows, b_scale=ws.get("psc_wvoc") if self.vgd == "f16x2" else None)
+                    a_scale=rows, b_scale=ws.get("psc_wvoc") if self.vgd == "f16x2" else None, big_tile="u" in self.BIG)
 
     def _vocab_weight_grad(self, ws, G0, scratch):
         """linear2vocab.weight's gradient G0^T . (coef * Hs) on the current stream."""
@@ -1301,7 +1306,7 @@ class A2CEngine:
             colsc, ev = self._g0_col_scales(ws, G0)
             torch.cuda.current_stream().wait_event(ev)   # (they may have been computed on another stream, beside the chains)
         self._pgemm(ws, "gvoc", G0, ws["HsC"], self.gP["linear2vocab.weight"], scratch, self.vgd, a_kmajor=True, b_kmajor=True,
-                    shared=True, a_scale=colsc)
+                    shared=True, a_scale=colsc, big_tile="g" in self.BIG)
 
     def _order_tokens(self, ws, n, rows, main, side, after=None):
         """The rows of the token matrix listed by token (what the reproducible embedding gradients sum by): it
@@ -1610,7 +1615,7 @@ class A2CEngine:
             ws["psc_" + key] = self._scale_of(ws, "p_" + key, w, True)
 
     def _pgemm(self, ws, tag, a, b, out, scratch, dtype, a_kmajor=False, b_kmajor=False, shared=False, a_scale=None,
-               b_scale=None):
+               b_scale=None, big_tile=False):
         """A product of the backward pass in the arithmetic `dtype` (hipabi.gemm_auto).  With "f16x2" the operands'
         scales are computed here, a pass over each, unless the caller hands them in (an operand of two products)."""
         if dtype == "f16x2":
@@ -1621,7 +1626,7 @@ class A2CEngine:
         else:
             a_scale = b_scale = None
         hip.gemm_auto(a, b, out, scratch, a_kmajor=a_kmajor, b_kmajor=b_kmajor, shared=shared, dtype=dtype, a_scale=a_scale,
-                      b_scale=b_scale)
+                      b_scale=b_scale, big_tile=big_tile)
 
     def _g0_row_scales(self, ws, G0):
         """Row scales of G0 = onehot(token) - softmax for the two-piece products, on the current stream, from the rows'

@@ -38,6 +38,8 @@ SIGNATURES = {
                                  c_vp, c_int, c_vp]),
     "icrl_gemm_f16x2s_splitk": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_int,
                                         c_int, c_int, c_vp]),
+    "icrl_gemm_f16x2s_splitk_tile": (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_int,
+                                        c_int, c_int, c_int, c_vp]),
     "icrl_absmax_scales": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "icrl_g0_row_scales": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "icrl_sum_slabs": (c_int, [c_vp, c_i64, c_int, c_i64, c_vp, c_int, c_vp]),
@@ -107,7 +109,7 @@ SIGNATURES = {
 
 SAMPLE, GREEDY, FORCED = 0, 1, 2
 EMIT_DLOGITS = 16   # or-ed into SAMPLE / FORCED: the probs output receives onehot(token) - softmax
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -581,8 +583,9 @@ def gemm_splitk(a, b, slabs, splits, *, a_kmajor=False, b_kmajor=False, tile=0, 
         for t, count in ((a_scale, m), (b_scale, n)):
             assert t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= count
         with _Timed("gemm_f16x2s", 2.0 * m * n * k, 4.0 * (m * k + k * n + splits * m * n)):
-            rc = load().icrl_gemm_f16x2s_splitk(_ptr(a), a.stride(0), int(a_kmajor), _ptr(a_scale), _ptr(b), b.stride(0),
-                                                int(b_kmajor), _ptr(b_scale), _ptr(slabs), n, m * n, m, n, k, splits, _stream())
+            rc = load().icrl_gemm_f16x2s_splitk_tile(_ptr(a), a.stride(0), int(a_kmajor), _ptr(a_scale), _ptr(b), b.stride(0),
+                                                     int(b_kmajor), _ptr(b_scale), _ptr(slabs), n, m * n, m, n, k, splits,
+                                                     int(tile), _stream())
         _check(rc, "icrl_gemm_f16x2s_splitk")
         return
     if dtype == "bf16":
@@ -653,7 +656,7 @@ def _plan_gemm(m, n, k, out_contiguous=True, shared=False):
 
 
 def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=False, bias=None, shared=False,
-              dtype="f32", a_scale=None, b_scale=None):
+              dtype="f32", a_scale=None, b_scale=None, big_tile=False):
     """gemm() with the tile / split-K choice of plan_gemm(); `scratch` is a flat float32 buffer for
     the split-K partial slabs (summed in a fixed order, so results are reproducible)."""
     m = a.shape[1] if a_kmajor else a.shape[0]
@@ -672,6 +675,18 @@ def gemm_auto(a, b, out, scratch, *, a_kmajor=False, b_kmajor=False, accumulate=
         tiles = ((m + 127) // 128) * ((n + 127) // 128)
         fits = [sp for sp in range(1, 9) if sp == 1 or (contiguous and k // sp >= 512)]
         tile, splits = 1, min(fits, key=lambda sp: (-(-tiles * sp // 512) / (tiles * sp / 512.0), -sp))
+    if big_tile and dtype == "f16x2" and contiguous and scratch is not None and m >= 256 and n >= 256:
+        # 256x256 tiles, one 512-thread workgroup per CU: the split whose workgroups fill whole turns of 256 places
+        # best, the larger one on a tie (always through the slab path: the large tile has no direct-store entry)
+        tiles = ((m + 255) // 256) * ((n + 255) // 256)
+        fits = [sp for sp in range(1, 9) if (sp == 1 or k // sp >= 512) and sp * m * n <= scratch.numel()]
+        if fits:
+            splits = min(fits, key=lambda sp: (-(-tiles * sp // 256) / (tiles * sp / 256.0), -sp))
+            slabs = scratch[:splits * m * n].view(splits, m, n)
+            gemm_splitk(a, b, slabs, splits, a_kmajor=a_kmajor, b_kmajor=b_kmajor, tile=2, dtype=dtype, a_scale=a_scale,
+                        b_scale=b_scale)
+            sum_slabs(slabs, out, accumulate=accumulate)
+            return out
     if splits > 1:  # no more partial slabs than the scratch buffer holds
         splits = min(splits, (scratch.numel() // (m * n)) if scratch is not None else 1)
     if splits > 1:

@@ -31,7 +31,7 @@ typedef void* icrl_stream_t;
 #define ICRL_ERR_HIP (-2)     /* a HIP runtime call failed */
 #define ICRL_ERR_TIMEOUT (-3) /* a chain kernel gave up waiting for a peer workgroup */
 
-#define ICRL_ABI_VERSION 3
+#define ICRL_ABI_VERSION 4
 
 int icrl_abi_version(void);
 const char* icrl_last_error(void);
@@ -128,6 +128,13 @@ int icrl_gemm_f16x2s(const float* A, int64_t lda, int a_kmajor, const float* a_s
 int icrl_gemm_f16x2s_splitk(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B,
                             int64_t ldb, int b_kmajor, const float* b_scale, float* C_slabs, int64_t ldc,
                             int64_t slab_stride, int M, int N, int K, int splits, icrl_stream_t stream);
+/* icrl_gemm_f16x2s_splitk with the tile shape chosen by the caller: tile 0 or 1 = 128 x 128 on 256 threads, 2 = 256 x 256
+   on 512 threads (one workgroup per CU; per element product half the operand bytes and half the cutting: the two
+   vocabulary-sized products of the backward pass, trainers.py:479 through models.py:82).  Same results to float32
+   rounding (the k order within a split is the same; bit-equal to the 128 x 128 tiles for the same splits). */
+int icrl_gemm_f16x2s_splitk_tile(const float* A, int64_t lda, int a_kmajor, const float* a_scale, const float* B,
+                                 int64_t ldb, int b_kmajor, const float* b_scale, float* C_slabs, int64_t ldc,
+                                 int64_t slab_stride, int M, int N, int K, int splits, int tile, icrl_stream_t stream);
 int icrl_absmax_scales(const float* x, int64_t ld, int rows, int cols, float* row_scale, float* col_scale,
                        unsigned* work, icrl_stream_t stream);
 int icrl_g0_row_scales(const float* log_prob, int count, float* scale, icrl_stream_t stream);

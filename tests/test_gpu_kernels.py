@@ -834,6 +834,39 @@ def test_f16x2s_gemm_layouts(a_km, b_km, shape):
     assert twice.max() < 2e-6
 
 
+@pytest.mark.parametrize("a_km", [False, True])
+@pytest.mark.parametrize("b_km", [False, True])
+@pytest.mark.parametrize("shape,splits", [((256, 256, 64), 1), ((300, 700, 333), 2), ((1000, 512, 2050), 3),
+                                          ((2560, 512, 9728), 6)])
+def test_f16x2s_gemm_on_256_tiles(a_km, b_km, shape, splits):
+    """icrl_gemm_f16x2s_splitk_tile with tile 2 (256 x 256, 512 threads): every layout, ragged tile rows and columns,
+    ragged k, against float64 - and bit for bit the slabs of the 128 x 128 tiles for the same splits (the k order
+    within a split, the pieces and their order are the same; only who computes which 32 x 32 block differs)."""
+    m, n, k = shape
+    rs = np.random.RandomState(m + n + k + 1)
+    a = rnd(rs, m, k) * np.exp(rs.standard_normal((m, 1)) * 4).astype(np.float32)
+    b = rnd(rs, n, k) * np.exp(rs.standard_normal((n, 1)) * 4).astype(np.float32)
+    a_st, b_st = dev(a.T.copy() if a_km else a), dev(b.T.copy() if b_km else b)
+    work = torch.zeros(max(m, n) + k, dtype=torch.int32, device="cuda")
+    sa, sb = torch.zeros(m, device="cuda"), torch.zeros(n, device="cuda")
+    hip.absmax_scales(a_st, work, **({"col_scale": sa} if a_km else {"row_scale": sa}))
+    hip.absmax_scales(b_st, work, **({"col_scale": sb} if b_km else {"row_scale": sb}))
+    big, std = torch.full((splits, m, n), float("nan"), device="cuda"), torch.empty(splits, m, n, device="cuda")
+    hip.gemm_splitk(a_st, b_st, big, splits, a_kmajor=a_km, b_kmajor=b_km, tile=2, dtype="f16x2", a_scale=sa, b_scale=sb)
+    hip.gemm_splitk(a_st, b_st, std, splits, a_kmajor=a_km, b_kmajor=b_km, tile=1, dtype="f16x2", a_scale=sa, b_scale=sb)
+    assert torch.equal(big, std)
+    want = a.astype(np.float64) @ b.astype(np.float64).T
+    bound = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T
+    err = np.abs(big.sum(0).cpu().numpy().astype(np.float64) - want) / bound
+    assert err.max() < 1e-6
+    # through gemm_auto, as the engine calls it
+    scratch = torch.empty(8 * m * n, device="cuda")
+    auto = torch.empty(m, n, device="cuda")
+    hip.gemm_auto(a_st, b_st, auto, scratch, a_kmajor=a_km, b_kmajor=b_km, shared=True, dtype="f16x2", a_scale=sa, b_scale=sb,
+                  big_tile=True)
+    assert (np.abs(auto.cpu().numpy().astype(np.float64) - want) / bound).max() < 1e-6
+
+
 # --------------------------------------------------------------------------- policy LSTM backward-through-time
 @pytest.mark.parametrize("n,t_steps,dtype", [(512, 19, "f32"), (48, 5, "f32"), (64, 3, "bf16")])
 def test_policy_lstm_bptt_equals_the_launches_issued_one_by_one_and_autograd(n, t_steps, dtype):

@@ -12,13 +12,14 @@ if len(sys.argv) > 1:   # another build of the library (kernel variants under te
 dev = torch.device("cuda", 0)
 def run(m, n, k, akm, bkm):
     a = torch.randn((k, m) if akm else (m, k), device=dev); b = torch.randn((k, n) if bkm else (n, k), device=dev)
-    out = torch.empty(m, n, device=dev); scratch = torch.empty(64 * m * n if m * n < 4e6 else 1, device=dev)
+    out = torch.empty(m, n, device=dev); scratch = torch.empty((64 if m * n < 4e6 else 8) * m * n, device=dev)
     work = torch.zeros(max(m, n) + k, dtype=torch.int32, device=dev)
     sa, sb = torch.zeros(m, device=dev), torch.zeros(n, device=dev)
     ka = {"col_scale": sa} if akm else {"row_scale": sa}; kb = {"col_scale": sb} if bkm else {"row_scale": sb}
     hip.absmax_scales(a, work, **ka); hip.absmax_scales(b, work, **kb)
     res = []
     for what, fn in (("f16x2", lambda: hip.gemm_auto(a, b, out, scratch, a_kmajor=akm, b_kmajor=bkm, shared=True, dtype="f16x2", a_scale=sa, b_scale=sb)),
+                     ("f16x2 on 256x256 tiles", lambda: hip.gemm_auto(a, b, out, scratch, a_kmajor=akm, b_kmajor=bkm, shared=True, dtype="f16x2", a_scale=sa, b_scale=sb, big_tile=True)),
                      ("f32x3", lambda: hip.gemm_auto(a, b, out, scratch, a_kmajor=akm, b_kmajor=bkm, shared=True, dtype="f32x3")),
                      ("scales a", lambda: hip.absmax_scales(a, work, **ka)), ("scales b", lambda: hip.absmax_scales(b, work, **kb))):
         for _ in range(3): fn()
