@@ -47,8 +47,9 @@ PIECE_KINDS = {"gemm_f32x3": 6, "gemm_f16x2s": 3, "gemm_f16x2": 3}
 PIECE_KERNELS = {
     "gemm_f32x3": "gemm_f32x3_kernel (three bf16 pieces per element, cut on chip: the backward pass's long products with "
                   "--grad-products f32x3)",
-    "gemm_f16x2s": "gemm_f16x2s_kernel (two scaled f16 pieces per element, cut on chip: the backward pass's long products - "
-                   "G0 . W, G0^T . Hs, the recurrent layers' weight and input gradients)",
+    "gemm_f16x2s": "gemm_f16x2s_kernel + gemm_f16x2s_big_kernel (two scaled f16 pieces per element, cut on chip: the backward "
+                   "pass's long products - G0 . W and G0^T . Hs on 256x256 tiles, the recurrent layers' weight and input "
+                   "gradients on 128x128 tiles)",
     "gemm_f16x2": "gemm_f16x2_kernel (operands cut once into two scaled f16 pieces in fragment order: the rollout's "
                   "per-round vocabulary/gate product and the per-word tables)"}
 
@@ -419,8 +420,11 @@ def main():
     pmc_t, pmc_m = load_profile("pmc_traffic.json"), load_profile("pmc_mfma.json")
 
     def pmc_traffic(kernel):
-        if pmc_t and kernel in pmc_t:
-            return pmc_t[kernel]["fetch_bytes_per_launch"] + pmc_t[kernel]["write_bytes_per_launch"]
+        # (a family's kernels together: bytes per launch weighted by their launch counts in the profiled run)
+        rows = [pmc_t[k] for k in (kernel, kernel.replace("_kernel", "_big_kernel")) if pmc_t and k in pmc_t]
+        launches = sum(r["launches"] for r in rows)
+        if launches:
+            return sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in rows) / launches
         return None
     traffic = pmc_traffic("gemm_f32_kernel")
     mfma_util = {k: v["mfma_utilisation"] for k, v in pmc_m.items() if isinstance(v, dict) and "mfma_utilisation" in v} \
