@@ -806,6 +806,7 @@ class A2CEngine:
         ws["policy_early"] = False
         ws.pop("early_pending", None)
         ws.pop("head_grads_pending", None)
+        self._forget_scales(ws)
         ws["tokT"].copy_(captions.t())
         self._rollout(ws, features, n, 1, s, None, hip.FORCED)
         self._order_tokens(ws, n, s * n, torch.cuda.current_stream(), torch.cuda.current_stream())
@@ -820,6 +821,7 @@ class A2CEngine:
         V, gV = self.V, self.gV
         n, p0 = captions.shape
         ws = self._buffers(n, p0, 1)
+        self._forget_scales(ws)
         main = torch.cuda.current_stream()
         ws["tokT"][:p0].copy_(captions.t())
         tok_flat = ws["tokT"].view(-1)
@@ -995,6 +997,7 @@ class A2CEngine:
         assert s >= 1 and p0 >= 1
         assert features.shape == (n, self.F) and features.dtype == torch.float32 and features.is_contiguous()
         ws = self._buffers(n, p0, s)
+        self._forget_scales(ws)
         P, V, R = self.P, self.V, self.R
         tokT = ws["tokT"]
         if mode == hip.FORCED:
@@ -1570,6 +1573,15 @@ class A2CEngine:
         hip.scale_rows(ws["uh"].expand(s * n, H), ws["dvalue"], ws["d_emit"].view(s * n, H))
         if weights:
             self._value_head_weight_grads(ws, features, n, s, ws["scratch_main"], ws["cs_main"])
+
+    @staticmethod
+    def _forget_scales(ws):
+        """Scales kept in the workspace from one product to the next (parameter columns, the policy LSTM's outputs)
+        belong to the minibatch that computed them: every entry point that shares the workspace drops them first, so
+        that a later pass never cuts operands with scales taken from older parameters (a row that has grown past its
+        old scale would overflow f16)."""
+        for k in [k for k in ws if isinstance(k, str) and k.startswith("psc_")]:
+            ws[k] = None
 
     def _scale_of(self, ws, key, x, cols):
         """Power-of-two scales for a two-piece f16 product (hipabi.gemm, dtype "f16x2"): one per row of x, or with

@@ -273,3 +273,36 @@ def test_policy_bptt_launch_that_gave_up_is_walked_again_step_by_step(monkeypatc
     assert len(calls) == 1, "the step took the one-launch BPTT (else this test checks nothing)"
     assert eng.launch_timeouts == 1 and res.status_host[3] == 0
     _same_step(res, grads, exact, g_exact)
+
+
+def test_scales_kept_in_a_workspace_do_not_outlive_their_minibatch():
+    """The two-piece products of the backward pass take some operands' power-of-two scales from the workspace (parameter
+    columns, the policy LSTM's outputs), where the A2C step leaves them once per minibatch.  The teacher-forced
+    pre-training step shares that workspace for the same shape: after the parameters have grown eightfold, its
+    gradients must equal those of an engine that never ran an A2C step (with the old scales the cut operands would
+    overflow f16)."""
+    n, caplen = 256, 9
+    cfg = dict(n=n, vocab=300, caplen=caplen, fdim=512, seed=39, level=None)
+    a2c, rew = _modules(cfg)
+    feats, caps = synthetic.make_minibatch(n, 300, caplen, 512, 39)
+    u = synthetic.make_uniforms(39, (caplen - 1) * n)
+    eng, _, _ = _step(a2c, rew, feats, caps, 1, caplen - 1, u)
+    with torch.no_grad():
+        a2c.policy_network.caption_embedding.weight.mul_(8.0)
+        a2c.policy_network.lstm.weight_ih_l0.mul_(8.0)
+    f, c = torch.from_numpy(feats).cuda(), torch.from_numpy(caps).cuda()
+    valid = torch.full((n,), caplen - 1, dtype=torch.int32, device="cuda")
+    weight = torch.full((n,), 1.0 / n, dtype=torch.float32, device="cuda")
+
+    def ce(engine):
+        loss = engine.policy_ce_step(f, c, valid, weight).clone()
+        torch.cuda.synchronize()
+        return loss, {k: p.grad.clone() for k, p in a2c.policy_network.named_parameters()}
+    loss, grads = ce(eng)
+    fresh = trainers.build_engine(a2c, rew)
+    loss_f, grads_f = ce(fresh)
+    assert torch.isfinite(loss).all() and torch.equal(loss, loss_f)
+    for k in grads_f:
+        assert torch.isfinite(grads[k]).all(), k
+        scale = grads_f[k].pow(2).mean().sqrt().item() + 1e-12
+        assert (grads[k] - grads_f[k]).abs().max().item() <= 1e-5 * scale, k
