@@ -306,3 +306,34 @@ def test_scales_kept_in_a_workspace_do_not_outlive_their_minibatch():
         assert torch.isfinite(grads[k]).all(), k
         scale = grads_f[k].pow(2).mean().sqrt().item() + 1e-12
         assert (grads[k] - grads_f[k]).abs().max().item() <= 1e-5 * scale, k
+
+
+@pytest.mark.parametrize("variant", ["value_bptt_first", "long_replay", "four_streams"])
+def test_schedule_variants_give_the_gradients_of_the_exact_kernels(variant):
+    """The backward pass's other queueing orders - the value chain's BPTT ahead of the policy LSTM's (the schedule before
+    the reordering), the policy network's weight gradients on the third stream (what a long replay check switches
+    to) and a stream of its own for the replay check - against the exact kernels: same tokens, values, rewards,
+    scalars and gradients.  Every order has to carry the same dependencies; only their timing differs."""
+    cfg = dict(n=256, vocab=300, caplen=9, fdim=512, seed=41, level=None)
+    a2c, rew = _modules(cfg)
+    feats, caps = synthetic.make_minibatch(256, 300, 9, 512, 41)
+    u = synthetic.make_uniforms(41, 8 * 256)
+    _, exact, g_exact = _step(a2c, rew, feats, caps, 1, 8, u, chain_mode="exact", collapse_replays=False)
+    opts, before = {}, None
+    if variant == "value_bptt_first":
+        opts["policy_bptt_first"] = False
+    elif variant == "long_replay":
+        def before(engine):
+            engine.LONG_REPLAY = 1
+    else:
+        def before(engine):
+            engine.max_streams = 4
+    eng, res, grads = _step(a2c, rew, feats, caps, 1, 8, u, before=before, **opts)
+    assert res.chain_plan[0][0] == "segmented" and res.full_calls < 8, "the step took the schedule under test"
+    _same_step(res, grads, exact, g_exact)
+    # and a second minibatch on the same engine (workspaces, events and kept scales of the first are in place)
+    res2 = eng.step(torch.from_numpy(feats).cuda(), torch.from_numpy(caps[:, :1]).cuda().contiguous(), 8,
+                    uniforms=torch.from_numpy(u).cuda()).check()
+    torch.cuda.synchronize()
+    grads2 = {k: p.grad.clone() for k, p in a2c.named_parameters()}
+    _same_step(res2, grads2, exact, g_exact)
