@@ -10,8 +10,11 @@ reference's Python loop; it computes the same numbers in a different order:
   2. once all tokens exist, the value network's batch-1 LSTM recurrence and the reward
      network's batch-1 GRU recurrence (models.py:133, 226 fed (N,1,E) without
      batch_first) run over every step's prefix, both chains at once;
-  3. loss (trainers.py:471-475), then the policy BPTT on one stream beside the value
-     chain's BPTT on the other.
+  3. loss (trainers.py:471-475), then the backward pass: the policy LSTM's BPTT and the value
+     chain's BPTT as one persistent launch each (the policy LSTM's first by default), the
+     products over all (step, row) positions - vocabulary, weight and input gradients - on two
+     more streams beside the value chain's BPTT and behind it; or, where the persistent launches
+     do not apply, the policy BPTT step by step on one stream beside the value chain's on another.
 
 The two recurrences can be evaluated in two ways (``chain_mode``):
   * "exact": the persistent kernels of chain.hip walk the ~10^5 dependent steps one by one;
@@ -243,7 +246,8 @@ class A2CEngine:
         # Greedy decoding always takes the exact kernel.
         assert rollout_arith in ("f32", "f16x2")
         self.rollout_arith = rollout_arith
-        # the policy LSTM's backward-through-time as one persistent launch behind the value chain's (see _tail_ok)
+        # the policy LSTM's backward-through-time as one persistent launch on the main stream, in front of the value
+        # chain's or behind it (policy_bptt_first; see _tail_ok)
         self.late_policy_bptt = bool(late_policy_bptt)
         self._warm16b_off, self._warm16b_penalty = 0, 32
         # positions a replay must have before it is left out (raised when a replay check fails; decays again)
@@ -506,8 +510,9 @@ class A2CEngine:
         return self.chain_arith == "f16x2" and self.persistent and hip.chain_bwd_f16x2_supported(rows)
 
     def _tail_ok(self, n, pv, pr, pb):
-        """Whether this attempt runs the backward pass in the order value chain BPTT -> policy LSTM BPTT (both
-        persistent launches on the main stream) -> weight gradients, with everything of the policy network's
+        """Whether this attempt runs the backward pass with the policy LSTM's BPTT and the value chain's BPTT as two
+        persistent launches on the main stream (the policy LSTM's first unless policy_bptt_first is off), the weight
+        gradients beside and behind the value chain's, and with everything of the policy network's
         backward pass that needs no BPTT (G0 . W, the vocabulary gradients) formed beside the value chain's BPTT
         instead of beside the forward chains.  As 3 T dependent launches on a stream of its own the policy LSTM's
         BPTT took as long as the value chain's (19 steps at 120 us, launch latency, not work) and its weight
