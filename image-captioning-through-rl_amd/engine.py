@@ -1686,8 +1686,9 @@ class A2CEngine:
     def _value_chain_backward(self, ws, n, p0, s, fc, main, side, plan, ev_loss, features=None, tail=False):
         """The value chain's BPTT and everything that consumes it.  With ev_loss the policy network's backward
         pass is queued as well (first attempt of a step): on the side stream beside the chain, or (tail, see
-        _tail_ok) its loss-dependent products beside the chain and its LSTM's BPTT as one launch behind the
-        chain's.  Without ev_loss only the chain's part is redone (after a rejected seam check)."""
+        _tail_ok) its LSTM's BPTT as one launch in front of the chain's (policy_bptt_first) or behind it and its
+        products over all positions beside the chain's launch.  Without ev_loss only the chain's part is redone
+        (after a rejected seam check)."""
         V, gV = self.V, self.gV
         lv, tv = p0 + s - 1, hip.chain_positions(n, p0, s, fc)
         tok_flat = ws["tokT"].view(-1)
