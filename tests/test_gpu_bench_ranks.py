@@ -69,11 +69,11 @@ def test_rccl_collectives_beside_the_persistent_chain_kernels_on_one_rank():
     every collective issued (ICRL_FORCE_COLLECTIVES=1) - the broadcast, the early all-reduce of the policy network's
     gradients on its own stream beside the value chain's persistent BPTT launch, the second piece, the max over
     ranks - at the metric's size.  No persistent launch may give up waiting for its workgroups, and the step may
-    cost at most 10 % more than the same run with no process group (measured: 1-8 %, 0.05-0.4 ms: three collectives'
-    host calls and single-rank kernels at the end of every step, where nothing hides them any more - the policy
-    network's gradients are complete about when the value network's are; a launch that gives up or a stream that
-    serialises behind a collective costs 20 % and more).  (More than one RCCL rank needs more than one GPU: that
-    stays unmeasured here.)"""
+    cost at most 5 % more than the same run with no process group (measured: 1-2 %, 0.05-0.1 ms: one all-reduce of
+    the flat buffer at the end of every step - the policy network's gradients are complete about when the value
+    network's are, so bench.py no longer sends them as a piece of their own; with three collectives a step it was
+    1-8 %; a launch that gives up or a stream that serialises behind a collective costs 20 % and more).  (More than one
+    RCCL rank needs more than one GPU: that stays unmeasured here.)"""
     size = ["--steps", "20", "--warmup", "5", "--soak", "0"]
     plain = _launch(1, size, backend="nccl")
     forced = _launch(1, size, backend="nccl", env_extra={"ICRL_FORCE_COLLECTIVES": "1"})
@@ -82,4 +82,4 @@ def test_rccl_collectives_beside_the_persistent_chain_kernels_on_one_rank():
     assert forced["parameters_identical_across_ranks"] is None   # one rank: nothing to compare
     print("ms per step: %.3f without a process group, %.3f with every collective issued over RCCL"
           % (plain["ms_per_step"], forced["ms_per_step"]))
-    assert forced["ms_per_step"] <= 1.10 * plain["ms_per_step"]
+    assert forced["ms_per_step"] <= 1.05 * plain["ms_per_step"]
